@@ -1,0 +1,179 @@
+#!/usr/bin/env python3
+"""Headline benchmark: persons/s of the ViTPose hot path on N MI355X (BASELINE.json).
+
+    python bench.py [--gpus N --steps K --warmup W] [--dtype fp16|bf16] [--batch 256]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the whole hot path (crop batch resident in HBM -> patch embed
+-> ViT encoder -> deconv head -> heatmaps -> arg-max/DARK-UDP decode -> keypoints in
+HBM, + the RCCL all-gather of keypoints when N > 1) over one batch of 256 synthetic
+256x192 crops per GPU (weak scaling: crops are independent, each rank owns its batch).
+Workload = BASELINE.json configs[1]: ViTPose-B COCO-17, batch 256, seeded random
+weights of that architecture, synthetic uniform-noise crops.
+
+Prints ONE JSON line on rank 0 with `roofline` (dominant kernel = the proj/fc2 GEMM,
+timed live with HIP events on the library's stream inside the timed region) and
+`cpu_baseline` (the oracle's torch-CPU per-crop path on this box's host cores, rank 0,
+N=1 only, bounded sample).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_MFMA_16BIT = 2.5e15   # dense bf16/fp16 MFMA peak, MI355X_MICROARCH.md (256 CU x 4096 FLOP/clk x 2.4 GHz)
+PEAK_HBM = 8.0e12
+
+
+def cpu_baseline(variant, dataset, budget_s=20.0):
+    """Reference-equivalent CPU path (oracle/ restatement of _inference_torch, per crop,
+    batch 1 exactly like VitInference) on a bounded sample of the same synthetic crops."""
+    import torch
+    from easy_vitpose_amd.configs import model_shape
+    from easy_vitpose_amd.synth import synthetic_crops, synthetic_state_dict
+    from oracle import vitpose_cpu as O
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    shp = model_shape(variant, dataset)
+    sd = O.to_torch_state_dict(synthetic_state_dict(shp, 0))
+    crops = synthetic_crops(64, 0, 'noise')
+    O.inference_torch(sd, shp.depth, shp.num_heads, crops[0])  # warm-up
+    n, t0 = 0, time.perf_counter()
+    while n < len(crops) and (time.perf_counter() - t0 < budget_s or n < 3):
+        O.inference_torch(sd, shp.depth, shp.num_heads, crops[n])
+        n += 1
+    dt = time.perf_counter() - t0
+    return {'value': round(n / dt, 3), 'unit': 'persons/s', 'cores': cores, 'kind': 'port',
+            'sample': f'{n} crops of the same workload, one at a time (pre_img -> torch fp32 model -> decode), '
+                      f'{dt:.1f} s, torch {torch.__version__} with {cores} threads'}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--dtype', default='fp16', choices=['fp16', 'bf16'])
+    ap.add_argument('--batch', type=int, default=256)
+    ap.add_argument('--variant', default='b')
+    ap.add_argument('--dataset', default='coco')
+    ap.add_argument('--input', default='f32', choices=['f32', 'u8'])
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--breakdown', action='store_true', help='extra untimed pass with every kernel family timed (stderr)')
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from easy_vitpose_amd import VitPoseHip
+    from easy_vitpose_amd.configs import model_shape
+    from easy_vitpose_amd.synth import synthetic_crops, synthetic_state_dict
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run'
+    assert torch.cuda.is_available(), 'bench.py needs an AMD GPU (the HIP path has no CPU fallback)'
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+
+    shp = model_shape(args.variant, args.dataset)
+    B, K = args.batch, shp.num_keypoints
+    eng = VitPoseHip(shp, synthetic_state_dict(shp, 0), dtype=args.dtype, device_id=local_rank, max_batch=B)
+    crops_u8 = synthetic_crops(B, seed=rank, kind='noise')
+    if args.input == 'u8':
+        d_crops = torch.from_numpy(crops_u8).to(dev)
+    else:  # what pre_img hands to the model: normalised float32 NCHW
+        mean = np.array([0.485, 0.456, 0.406]); std = np.array([0.229, 0.224, 0.225])
+        x = ((crops_u8.astype(np.float64) / 255 - mean) / std).transpose(0, 3, 1, 2).astype(np.float32)
+        d_crops = torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+    d_out = torch.zeros((B, K, 3), dtype=torch.float32, device=dev)
+    d_all = torch.zeros((world * B, K, 3), dtype=torch.float32, device=dev) if world > 1 else None
+    torch.cuda.synchronize()
+
+    def step():
+        eng.infer_device(d_crops, d_out, sync=(world > 1))   # library stream; sync hands over to torch's stream
+        if world > 1:
+            dist.all_gather_into_tensor(d_all, d_out)        # RCCL over xGMI, [world*B, K, 3]
+
+    def fence():
+        eng.synchronize()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    dom = 'gemm_proj_fc2'
+    eng.set_profiling([dom])
+    eng.reset_profile()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    prof = eng.profile()
+    eng.set_profiling(False)
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    assert torch.isfinite(d_out).all(), 'non-finite keypoints'
+
+    breakdown = None
+    if args.breakdown and rank == 0:
+        eng.set_profiling(True); eng.reset_profile()
+        for _ in range(3):
+            eng.infer_device(d_crops, d_out, sync=True)
+        p = eng.profile(); eng.set_profiling(False)
+        breakdown = {k: {'ms_per_step': round(v['ms'] / 3, 4), 'launches_per_step': v['launches'] // 3,
+                         'tflops': round(v['flops'] / max(v['ms'], 1e-9) / 1e9, 1),
+                         'gbps': round(v['bytes'] / max(v['ms'], 1e-9) / 1e6, 1)} for k, v in p.items()}
+        print(json.dumps({'breakdown': breakdown}), file=sys.stderr)
+
+    if rank == 0:
+        persons_s = world * B * args.steps / dt
+        d = prof[dom]
+        ach = d['flops'] / (d['ms'] * 1e-3) if d['ms'] > 0 else 0.0
+        line = {
+            'metric': 'persons_per_sec', 'value': round(persons_s, 1), 'unit': 'persons/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': round(dt / args.steps * 1e3, 4), 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
+            'config': {'workload': f'ViTPose-{args.variant.upper()} {args.dataset} K={K}, batch {B} x 256x192 crops per GPU '
+                                   f'({args.input} input resident in HBM) -> (y,x,conf) keypoints in HBM'
+                                   + (', RCCL all-gather of keypoints' if world > 1 else ''),
+                       'global_batch': world * B, 'weights': 'seeded random init (no checkpoint offline)',
+                       'gflop_per_person': round(shp.gflop_per_person(), 3)},
+            'model_tflops': round(persons_s * shp.gflop_per_person() / 1e3, 1),
+            'model_frac_of_mfma_peak': round(persons_s * shp.gflop_per_person() * 1e9 / PEAK_MFMA_16BIT, 4),
+            'roofline': {'bound': 'mfma', 'kernel': 'gemm_kernel<EPI_BIAS_RESID> (attn.proj + mlp.fc2, fp32 residual epilogue)',
+                         'achieved': round(ach / 1e12, 2), 'peak': PEAK_MFMA_16BIT / 1e12, 'unit': 'TFLOP/s',
+                         'frac': round(ach / PEAK_MFMA_16BIT, 4), 'traffic': None,
+                         'launches': d['launches'], 'avg_launch_ms': round(d['ms'] / max(d['launches'], 1), 5),
+                         'flops_per_launch_avg': d['flops'] / max(d['launches'], 1)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line['cpu_baseline'] = cpu_baseline(args.variant, args.dataset)
+        else:
+            line['cpu_baseline'] = None
+        print(json.dumps(line), flush=True)
+    eng.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

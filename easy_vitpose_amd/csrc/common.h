@@ -1,0 +1,80 @@
+// Shared device helpers for the gfx950 (CDNA4) ViTPose kernels.
+// Wave = 64 lanes; MFMA 16x16x32 f16/bf16 with fp32 accumulation.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace vp {
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+
+struct F16 {};   // operand type tags
+struct BF16 {};
+
+// ---- scalar conversions (fp32 <-> 16-bit storage, round to nearest even) ----
+template <class T> __device__ __forceinline__ uint16_t to_bits(float v);
+template <> __device__ __forceinline__ uint16_t to_bits<F16>(float v) {
+    // saturate instead of overflowing to inf: activations are bounded in practice,
+    // but a clamp is cheaper than a NaN three layers later
+    v = fminf(fmaxf(v, -65504.f), 65504.f);
+    _Float16 h = (_Float16)v;
+    return __builtin_bit_cast(uint16_t, h);
+}
+template <> __device__ __forceinline__ uint16_t to_bits<BF16>(float v) {
+    uint32_t u = __builtin_bit_cast(uint32_t, v);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);  // NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+template <class T> __device__ __forceinline__ float from_bits(uint16_t b);
+template <> __device__ __forceinline__ float from_bits<F16>(uint16_t b) {
+    return (float)__builtin_bit_cast(_Float16, b);
+}
+template <> __device__ __forceinline__ float from_bits<BF16>(uint16_t b) {
+    return __builtin_bit_cast(float, (uint32_t)b << 16);
+}
+template <class T> __device__ __forceinline__ uint32_t pack2(float lo, float hi) {
+    return (uint32_t)to_bits<T>(lo) | ((uint32_t)to_bits<T>(hi) << 16);
+}
+
+// ---- MFMA: D(16x16) += A(16x32) * B(32x16) ----
+// fragment layout (gfx950): A lane l holds A[row = l&15][k = (l>>4)*8 .. +7],
+//                           B lane l holds B[k = (l>>4)*8 .. +7][col = l&15],
+//                           C lane l holds C[row = (l>>4)*4 + r][col = l&15], r = 0..3
+template <class T> __device__ __forceinline__ f32x4 mfma16(u32x4 a, u32x4 b, f32x4 c);
+template <> __device__ __forceinline__ f32x4 mfma16<F16>(u32x4 a, u32x4 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+template <> __device__ __forceinline__ f32x4 mfma16<BF16>(u32x4 a, u32x4 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef __attribute__((address_space(1))) const void* gbl_ptr_t;
+
+// async global -> LDS, 16 B per lane; LDS destination = wave-uniform base + lane*16
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((gbl_ptr_t)gsrc, (lds_ptr_t)lds_wave_base, 16, 0, 0);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// XCD-aware, bijective block remap: the dispatcher places block b on XCD b % 8; give
+// every XCD one contiguous range of logical tiles so neighbouring tiles (which share
+// operand panels) hit the same private L2.
+__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
+    const int q = nblk >> 3, r = nblk & 7;
+    const int xcd = bid & 7, idx = bid >> 3;
+    const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + idx;
+}
+
+}  // namespace vp

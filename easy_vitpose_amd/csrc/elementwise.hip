@@ -1,0 +1,137 @@
+// HBM-bound helpers of the ViTPose path: patch gather (im2col) and LayerNorm.
+#include "common.h"
+#include "kernels.h"
+#include "../../include/vitpose_hip.h"
+
+namespace vp {
+
+// ------------------------------------------------------------------ im2col
+// PatchEmbed = Conv2d(3, D, k=16, s=16, padding=2) (vit.py:222): patch (py,px) covers
+// rows 16py-2 .. 16py+13, cols 16px-2 .. 16px+13 of the 256x192 crop, zero outside.
+// Row m = b*192 + py*12 + px of the patch matrix, column k = c*256 + ky*16 + kx
+// (the flattening of the conv weight [D,3,16,16]).  One thread = one 16-byte chunk
+// (8 consecutive kx) of the output.
+template <class Ty, int FMT>
+__global__ __launch_bounds__(256) void im2col_kernel(const void* __restrict__ in, uint16_t* __restrict__ out, int B) {
+    const size_t total = (size_t)B * 192 * 96;
+    for (size_t id = (size_t)blockIdx.x * 256 + threadIdx.x; id < total; id += (size_t)gridDim.x * 256) {
+        const int kc = (int)(id % 96);
+        const size_t m = id / 96;
+        const int c = kc >> 5, ky = (kc & 31) >> 1, kx0 = (kc & 1) * 8;
+        const int t = (int)(m % 192), b = (int)(m / 192);
+        const int py = t / 12, px = t % 12;
+        const int y = 16 * py - 2 + ky;
+        const int x0 = 16 * px - 2 + kx0;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int x = x0 + e;
+            float f = 0.f;
+            if ((unsigned)y < 256u && (unsigned)x < 192u) {
+                if (FMT == VP_INPUT_F32_NCHW) {
+                    f = ((const float*)in)[(((size_t)b * 3 + c) * 256 + y) * 192 + x];
+                } else {
+                    // pre_img (easy_ViTPose/inference.py:316-317): float64 x/255, (x-MEAN)/STD, cast to fp32
+                    const double mean = c == 0 ? 0.485 : (c == 1 ? 0.456 : 0.406);
+                    const double stdv = c == 0 ? 0.229 : (c == 1 ? 0.224 : 0.225);
+                    const uint8_t u = ((const uint8_t*)in)[(((size_t)b * 256 + y) * 192 + x) * 3 + c];
+                    f = (float)(((double)u / 255.0 - mean) / stdv);
+                }
+            }
+            v[e] = f;
+        }
+        u32x4 o;
+        o[0] = pack2<Ty>(v[0], v[1]);
+        o[1] = pack2<Ty>(v[2], v[3]);
+        o[2] = pack2<Ty>(v[4], v[5]);
+        o[3] = pack2<Ty>(v[6], v[7]);
+        *(u32x4*)(out + id * 8) = o;
+    }
+}
+
+hipError_t im2col_launch(int dtype, const void* crops, int fmt, uint16_t* out, int B, hipStream_t s) {
+    const size_t total = (size_t)B * 192 * 96;
+    int grid = (int)((total + 255) / 256);
+    if (grid > 8192) grid = 8192;
+#define VP_I2C(TY, F) hipLaunchKernelGGL((im2col_kernel<TY, F>), dim3(grid), dim3(256), 0, s, crops, out, B)
+    if (fmt == VP_INPUT_F32_NCHW) {
+        if (dtype == DT_F16) VP_I2C(F16, VP_INPUT_F32_NCHW); else VP_I2C(BF16, VP_INPUT_F32_NCHW);
+    } else if (fmt == VP_INPUT_U8_NHWC) {
+        if (dtype == DT_F16) VP_I2C(F16, VP_INPUT_U8_NHWC); else VP_I2C(BF16, VP_INPUT_U8_NHWC);
+    } else {
+        return hipErrorInvalidValue;
+    }
+#undef VP_I2C
+    return hipGetLastError();
+}
+
+// --------------------------------------------------------------- LayerNorm
+// nn.LayerNorm(eps=1e-6) (vit.py:274) over the fp32 residual stream, one wave per
+// token row, row held in registers (D <= 1280 -> <= 5 float4 per lane), two-pass
+// mean / variance in fp32, output rounded once to the GEMM operand type.
+template <class Ty>
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, uint16_t* __restrict__ out16,
+                                                        float* __restrict__ out32, int M, int D) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const int nv = D >> 2;
+    const f32x4* xr = (const f32x4*)(x + (size_t)row * D);
+    f32x4 v[5];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        const int idx = lane + 64 * i;
+        v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (idx < nv) {
+            v[i] = xr[idx];
+            sum += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+        }
+    }
+    const float mean = wave_sum(sum) / (float)D;
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        const int idx = lane + 64 * i;
+        if (idx < nv) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float d = v[i][e] - mean;
+                sq += d * d;
+            }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(sq) / (float)D + 1e-6f);
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        const int idx = lane + 64 * i;
+        if (idx < nv) {
+            const f32x4 g = ((const f32x4*)gamma)[idx];
+            const f32x4 b = ((const f32x4*)beta)[idx];
+            f32x4 y;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) y[e] = (v[i][e] - mean) * rstd * g[e] + b[e];
+            if (out16) {
+                u32x2 o;
+                o[0] = pack2<Ty>(y[0], y[1]);
+                o[1] = pack2<Ty>(y[2], y[3]);
+                ((u32x2*)(out16 + (size_t)row * D))[idx] = o;
+            }
+            if (out32) ((f32x4*)(out32 + (size_t)row * D))[idx] = y;
+        }
+    }
+}
+
+hipError_t layernorm_launch(int dtype, const float* x, const float* gamma, const float* beta, uint16_t* out16,
+                            float* out32, int M, int D, hipStream_t s) {
+    if ((D & 3) || D > 1280) return hipErrorInvalidValue;
+    const int grid = (M + 3) / 4;
+    if (dtype == DT_F16)
+        hipLaunchKernelGGL(layernorm_kernel<F16>, dim3(grid), dim3(256), 0, s, x, gamma, beta, out16, out32, M, D);
+    else
+        hipLaunchKernelGGL(layernorm_kernel<BF16>, dim3(grid), dim3(256), 0, s, x, gamma, beta, out16, out32, M, D);
+    return hipGetLastError();
+}
+
+}  // namespace vp

@@ -1,0 +1,52 @@
+// Internal launch interface between the C-ABI translation unit and the kernel
+// translation units.  Everything here is host-side C++; kernels live in *.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace vp {
+
+enum { DT_F16 = 0, DT_BF16 = 1 };
+
+// ----------------------------------------------------------------------- GEMM
+// C[m][n] = sum_k A[m][k] * W[n][k]   (A activations, W = nn.Linear weight [out,in])
+enum GemmEpi {
+    EPI_BIAS = 0,        // + bias            -> 16-bit [M, ldo]           (qkv)
+    EPI_BIAS_GELU = 1,   // gelu(+ bias)      -> 16-bit [M, ldo]           (fc1)
+    EPI_BIAS_RESID = 2,  // + bias + aux[m]   -> fp32   [M, ldo] (aux may alias out: proj, fc2)
+    EPI_POS = 3,         // + aux[m % 192]    -> fp32   [M, ldo]           (patch embed; bias folded into aux)
+    EPI_DECONV = 4,      // relu(+ bias)      -> 16-bit NHWC, output-parity scatter (deconv + folded BN + ReLU)
+    EPI_HEATMAP = 5,     // + bias            -> fp32 NCHW heatmaps [B, Kp, 64*48]  (final 1x1 conv)
+};
+enum GemmAMode { A_DENSE = 0, A_DECONV = 1 };
+
+struct GemmArgs {
+    const uint16_t* A;    // dense: [M, K] row-major.  deconv: NHWC source [B, Hin, Win, Cin]
+    const uint16_t* W;    // [Npad, K] row-major, Npad % 128 == 0 (deconv: 4 parity slabs of [Npad, K])
+    const float* bias;    // [Npad]
+    void* out;
+    const float* aux;     // residual [M, ldo] / pos [192, ldo]
+    int M, N, K, ldo;     // N = real columns (stores are masked to n < N)
+    int Hin, Win, Cin;    // deconv geometry (K = 4 * Cin)
+    const uint16_t* zero; // >= 128 B of zeros (deconv border taps)
+    int Kp;               // heatmap: number of keypoints (== N)
+};
+hipError_t gemm_launch(int dtype, int epi, const GemmArgs& a, hipStream_t s);
+
+// ------------------------------------------------------------------ attention
+// qkv [B*192, 3*D] 16-bit (columns = [q | k | v] x heads x head_dim, vit.py:166-167)
+// out [B*192, D]   16-bit (columns = heads x head_dim, vit.py:176)
+hipError_t attention_launch(int dtype, const uint16_t* qkv, uint16_t* out, int B, int D, int heads, hipStream_t s);
+
+// ---------------------------------------------------------------- elementwise
+// fp32 [M, D] -> LayerNorm(eps 1e-6) -> 16-bit [M, D] (out16) and/or fp32 (out32), either may be null
+hipError_t layernorm_launch(int dtype, const float* x, const float* gamma, const float* beta,
+                            uint16_t* out16, float* out32, int M, int D, hipStream_t s);
+// crops -> im2col patch matrix [B*192, 768] 16-bit (k = c*256 + ky*16 + kx, zero border of 2 px)
+hipError_t im2col_launch(int dtype, const void* crops, int input_format, uint16_t* out, int B, hipStream_t s);
+
+// --------------------------------------------------------------------- decode
+// heatmaps fp32 [N, K, 64, 48] -> out fp32 [N, K, 3] (y, x, conf); org_wh int32 [N,2] or null
+hipError_t decode_launch(const float* hm, const int32_t* org_wh, float* out, int N, int K, hipStream_t s);
+
+}  // namespace vp

@@ -1,0 +1,652 @@
+// C ABI (include/vitpose_hip.h) of the MI355X-native ViTPose hot path:
+// context + weight packer + forward orchestration.  No CPU fallback anywhere:
+// every compute entry point needs a HIP device and fails with VP_ERR_HIP otherwise.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/vitpose_hip.h"
+#include "kernels.h"
+
+namespace {
+
+thread_local std::string g_create_error;
+
+// fp32 -> 16-bit storage on the host (round to nearest even), same as the device paths
+uint16_t host_to_bits(float v, int dtype) {
+    uint32_t u;
+    std::memcpy(&u, &v, 4);
+    if (dtype == vp::DT_BF16) {
+        if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
+        u += 0x7fffu + ((u >> 16) & 1u);
+        return (uint16_t)(u >> 16);
+    }
+    // IEEE binary16, RNE, with subnormals; saturate to +-65504
+    const uint32_t sign = (u >> 16) & 0x8000u;
+    const uint32_t a = u & 0x7fffffffu;
+    if (a > 0x7f800000u) return (uint16_t)(sign | 0x7e00u);
+    if (a >= 0x477ff000u) return (uint16_t)(sign | 0x7bffu);   // >= 65520 rounds past max -> saturate
+    if (a < 0x33000001u) return (uint16_t)sign;                // < 2^-25 -> 0
+    int e = (int)(a >> 23) - 127;
+    uint32_t m = (a & 0x7fffffu) | 0x800000u;
+    if (e < -14) {                                             // subnormal half
+        const int shift = -14 - e + 13;
+        const uint32_t r = m >> shift, rem = m & ((1u << shift) - 1), half = 1u << (shift - 1);
+        uint32_t h = r;
+        if (rem > half || (rem == half && (r & 1))) ++h;
+        return (uint16_t)(sign | h);
+    }
+    uint32_t h = ((uint32_t)(e + 15) << 10) | ((m >> 13) & 0x3ffu);
+    const uint32_t rem = m & 0x1fffu;
+    if (rem > 0x1000u || (rem == 0x1000u && (h & 1))) ++h;
+    return (uint16_t)(sign | h);
+}
+
+struct Block {
+    float *ln1_g, *ln1_b, *ln2_g, *ln2_b;
+    uint16_t *w_qkv, *w_proj, *w_fc1, *w_fc2;
+    float *b_qkv, *b_proj, *b_fc1, *b_fc2;
+};
+
+}  // namespace
+
+struct vp_ctx {
+    vp_config cfg;
+    int D, L, heads, Kp, dtype, maxb;
+    hipStream_t stream = nullptr;
+    std::string err;
+    bool loaded = false;
+    std::vector<void*> allocs;
+    // weights
+    uint16_t* w_patch = nullptr;
+    float* pos = nullptr;
+    std::vector<Block> blocks;
+    float *lnf_g = nullptr, *lnf_b = nullptr;
+    uint16_t *w_d1 = nullptr, *w_d2 = nullptr, *w_fin = nullptr;
+    float *b_d1 = nullptr, *b_d2 = nullptr, *b_fin = nullptr, *b_zero = nullptr;
+    uint16_t* zero = nullptr;
+    // workspaces
+    void* in_stage = nullptr;
+    int32_t* wh_stage = nullptr;
+    float* x = nullptr;
+    uint16_t *y = nullptr, *qkv = nullptr, *hid = nullptr, *d1 = nullptr, *d2 = nullptr;
+    float *hm = nullptr, *kp = nullptr, *tok = nullptr;
+    // profiling
+    uint32_t prof = 0;   // bit f = time kernel family f
+    struct Ev { hipEvent_t a, b; int fam; double flops, bytes; };
+    std::vector<Ev> evs;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
+    vp_profile acc{};
+};
+
+namespace {
+
+int fail(vp_ctx* c, int code, const std::string& msg) {
+    if (c) c->err = msg; else g_create_error = msg;
+    return code;
+}
+
+#define HIPCHK(c, expr)                                                                         \
+    do {                                                                                        \
+        hipError_t e__ = (expr);                                                                \
+        if (e__ != hipSuccess)                                                                  \
+            return fail((c), VP_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e__));   \
+    } while (0)
+
+template <class T> int dalloc(vp_ctx* c, T** p, size_t count) {
+    void* q = nullptr;
+    HIPCHK(c, hipMalloc(&q, count * sizeof(T) + 256));
+    c->allocs.push_back(q);
+    *p = (T*)q;
+    return VP_OK;
+}
+
+int upload_f32(vp_ctx* c, float** dst, const float* src, size_t n, size_t npad = 0) {
+    if (npad < n) npad = n;
+    std::vector<float> tmp(npad, 0.f);
+    std::memcpy(tmp.data(), src, n * 4);
+    int rc = dalloc(c, dst, npad);
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpy(*dst, tmp.data(), npad * 4, hipMemcpyHostToDevice));
+    return VP_OK;
+}
+
+// rows x cols fp32 matrix -> 16-bit, rows padded with zeros to rows_pad
+int upload_mat(vp_ctx* c, uint16_t** dst, const float* src, size_t rows, size_t cols, size_t rows_pad) {
+    std::vector<uint16_t> tmp(rows_pad * cols, 0);
+    for (size_t i = 0; i < rows * cols; ++i) tmp[i] = host_to_bits(src[i], c->dtype);
+    int rc = dalloc(c, dst, rows_pad * cols);
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpy(*dst, tmp.data(), tmp.size() * 2, hipMemcpyHostToDevice));
+    return VP_OK;
+}
+
+size_t pad128(size_t n) { return (n + 127) / 128 * 128; }
+
+struct Lookup {
+    std::unordered_map<std::string, const vp_tensor_desc*> map;
+    vp_ctx* c;
+    int get(const std::string& name, int64_t numel, const float** out) {
+        auto it = map.find(name);
+        if (it == map.end()) return fail(c, VP_ERR_MISSING_TENSOR, "missing key in state dict: " + name);
+        if (it->second->numel != numel || it->second->data == nullptr)
+            return fail(c, VP_ERR_SHAPE, "size mismatch for " + name + ": expected " + std::to_string(numel) +
+                                             " elements, got " + std::to_string(it->second->numel));
+        *out = it->second->data;
+        return VP_OK;
+    }
+};
+
+// ConvTranspose2d(Cin, 256, 4, s=2, p=1, bias=False) + BatchNorm2d(eval, eps=1e-5)
+// (topdown_heatmap_simple_head.py:291-321) -> 4 output-parity GEMM operands
+//   Wp[parity=(a,b)][o][t*Cin + c] = w[c][o][ky(a,ti)][kx(b,tj)] * gamma[o]/sqrt(var[o]+eps),  t = ti*2+tj
+//   a=0: ti=0 -> ky=1 (input row i), ti=1 -> ky=3 (row i-1);  a=1: ti=0 -> ky=0 (row i+1), ti=1 -> ky=2 (row i)
+//   bias[o] = beta[o] - mean[o]*scale[o]
+int pack_deconv(vp_ctx* c, Lookup& lk, int idx, int Cin, uint16_t** w_out, float** b_out) {
+    const std::string h = "keypoint_head.deconv_layers.";
+    const float *w, *g, *b, *mu, *var;
+    int rc;
+    if ((rc = lk.get(h + std::to_string(idx) + ".weight", (int64_t)Cin * 256 * 16, &w))) return rc;
+    if ((rc = lk.get(h + std::to_string(idx + 1) + ".weight", 256, &g))) return rc;
+    if ((rc = lk.get(h + std::to_string(idx + 1) + ".bias", 256, &b))) return rc;
+    if ((rc = lk.get(h + std::to_string(idx + 1) + ".running_mean", 256, &mu))) return rc;
+    if ((rc = lk.get(h + std::to_string(idx + 1) + ".running_var", 256, &var))) return rc;
+    std::vector<float> scale(256), bias(256);
+    for (int o = 0; o < 256; ++o) {
+        scale[o] = g[o] / std::sqrt(var[o] + 1e-5f);
+        bias[o] = b[o] - mu[o] * scale[o];
+    }
+    const size_t K = (size_t)4 * Cin;
+    std::vector<float> wp((size_t)4 * 256 * K);
+    for (int pa = 0; pa < 2; ++pa)
+        for (int pb = 0; pb < 2; ++pb)
+            for (int o = 0; o < 256; ++o)
+                for (int ti = 0; ti < 2; ++ti)
+                    for (int tj = 0; tj < 2; ++tj) {
+                        const int ky = pa ? (ti ? 2 : 0) : (ti ? 3 : 1);
+                        const int kx = pb ? (tj ? 2 : 0) : (tj ? 3 : 1);
+                        float* dst = &wp[(((size_t)(pa * 2 + pb) * 256 + o) * 4 + (ti * 2 + tj)) * Cin];
+                        for (int ci = 0; ci < Cin; ++ci)
+                            dst[ci] = w[(((size_t)ci * 256 + o) * 4 + ky) * 4 + kx] * scale[o];
+                    }
+    if ((rc = upload_mat(c, w_out, wp.data(), (size_t)4 * 256, K, (size_t)4 * 256))) return rc;
+    return upload_f32(c, b_out, bias.data(), 256);
+}
+
+bool prof_begin(vp_ctx* c, int fam, double flops, double bytes) {
+    if (!((c->prof >> fam) & 1u)) return false;
+    std::pair<hipEvent_t, hipEvent_t> p;
+    if (!c->ev_pool.empty()) {
+        p = c->ev_pool.back();
+        c->ev_pool.pop_back();
+    } else {
+        hipEventCreate(&p.first);
+        hipEventCreate(&p.second);
+    }
+    hipEventRecord(p.first, c->stream);
+    c->evs.push_back({p.first, p.second, fam, flops, bytes});
+    return true;
+}
+void prof_end(vp_ctx* c, bool on) {
+    if (on) hipEventRecord(c->evs.back().b, c->stream);
+}
+void prof_collect(vp_ctx* c) {
+    for (auto& e : c->evs) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) {
+            c->acc.ms[e.fam] += ms;
+            c->acc.flops[e.fam] += e.flops;
+            c->acc.bytes[e.fam] += e.bytes;
+            c->acc.launches[e.fam] += 1;
+        }
+        c->ev_pool.push_back({e.a, e.b});
+    }
+    c->evs.clear();
+}
+
+#define LAUNCH(c, fam, flops, bytes, expr)   \
+    do {                                     \
+        const bool on__ = prof_begin((c), (fam), (flops), (bytes)); \
+        hipError_t e__ = (expr);             \
+        prof_end((c), on__);                 \
+        if (e__ != hipSuccess)               \
+            return fail((c), VP_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e__)); \
+    } while (0)
+
+int gemm(vp_ctx* c, int fam, int epi, const uint16_t* A, const uint16_t* W, const float* bias, void* out,
+         const float* aux, int M, int N, int K, int ldo, int Hin = 0, int Win = 0, int Cin = 0) {
+    vp::GemmArgs g{};
+    g.A = A; g.W = W; g.bias = bias; g.out = out; g.aux = aux;
+    g.M = M; g.N = N; g.K = K; g.ldo = ldo;
+    g.Hin = Hin; g.Win = Win; g.Cin = Cin; g.zero = c->zero; g.Kp = c->Kp;
+    const double par = (epi == vp::EPI_DECONV) ? 4.0 : 1.0;
+    const double flops = 2.0 * M * (double)N * K * par;
+    // algorithmic HBM bytes: each operand once, output once (+ residual read)
+    const double out_b = (epi == vp::EPI_BIAS_RESID || epi == vp::EPI_POS || epi == vp::EPI_HEATMAP) ? 4.0 : 2.0;
+    double bytes = 2.0 * M * (double)(epi == vp::EPI_DECONV ? Cin : K) + 2.0 * N * (double)K * par + out_b * M * (double)N * par;
+    if (epi == vp::EPI_BIAS_RESID) bytes += 4.0 * M * (double)N;
+    LAUNCH(c, fam, flops, bytes, vp::gemm_launch(c->dtype, epi, g, c->stream));
+    return VP_OK;
+}
+
+// forward of one chunk (n <= max_batch) with device-resident crops; heatmaps land in c->hm
+int forward_chunk(vp_ctx* c, const void* d_crops, int fmt, int n, bool want_tokens) {
+    const int D = c->D, M = n * 192;
+    const double in_b = (fmt == VP_INPUT_F32_NCHW ? 4.0 : 1.0) * n * 3.0 * 256 * 192;
+    LAUNCH(c, VP_PROF_IM2COL, 0.0, in_b + 2.0 * M * 768, vp::im2col_launch(c->dtype, d_crops, fmt, c->hid, n, c->stream));
+    int rc;
+    if ((rc = gemm(c, VP_PROF_GEMM_PATCH, vp::EPI_POS, c->hid, c->w_patch, c->b_zero, c->x, c->pos, M, D, 768, D))) return rc;
+    for (int l = 0; l < c->L; ++l) {
+        const Block& b = c->blocks[l];
+        LAUNCH(c, VP_PROF_LAYERNORM, 0.0, 6.0 * M * D,
+               vp::layernorm_launch(c->dtype, c->x, b.ln1_g, b.ln1_b, c->y, nullptr, M, D, c->stream));
+        if ((rc = gemm(c, VP_PROF_GEMM_QKV, vp::EPI_BIAS, c->y, b.w_qkv, b.b_qkv, c->qkv, nullptr, M, 3 * D, D, 3 * D))) return rc;
+        LAUNCH(c, VP_PROF_ATTN, 4.0 * 192 * 192 * (double)D * n, 8.0 * M * D,
+               vp::attention_launch(c->dtype, c->qkv, c->y, n, D, c->heads, c->stream));
+        if ((rc = gemm(c, VP_PROF_GEMM_PROJ, vp::EPI_BIAS_RESID, c->y, b.w_proj, b.b_proj, c->x, c->x, M, D, D, D))) return rc;
+        LAUNCH(c, VP_PROF_LAYERNORM, 0.0, 6.0 * M * D,
+               vp::layernorm_launch(c->dtype, c->x, b.ln2_g, b.ln2_b, c->y, nullptr, M, D, c->stream));
+        if ((rc = gemm(c, VP_PROF_GEMM_FC1, vp::EPI_BIAS_GELU, c->y, b.w_fc1, b.b_fc1, c->hid, nullptr, M, 4 * D, D, 4 * D))) return rc;
+        if ((rc = gemm(c, VP_PROF_GEMM_PROJ, vp::EPI_BIAS_RESID, c->hid, b.w_fc2, b.b_fc2, c->x, c->x, M, D, 4 * D, D))) return rc;
+    }
+    LAUNCH(c, VP_PROF_LAYERNORM, 0.0, 6.0 * M * D,
+           vp::layernorm_launch(c->dtype, c->x, c->lnf_g, c->lnf_b, c->y, want_tokens ? c->tok : nullptr, M, D, c->stream));
+    // head: tokens [n,16,12,D] (NHWC view of [n*192, D]) -> [n,32,24,256] -> [n,64,48,256] -> heatmaps [n,Kp,64,48]
+    if ((rc = gemm(c, VP_PROF_GEMM_DECONV, vp::EPI_DECONV, c->y, c->w_d1, c->b_d1, c->d1, nullptr, n * 192, 256, 4 * D, 256, 16, 12, D))) return rc;
+    if ((rc = gemm(c, VP_PROF_GEMM_DECONV, vp::EPI_DECONV, c->d1, c->w_d2, c->b_d2, c->d2, nullptr, n * 768, 256, 1024, 256, 32, 24, 256))) return rc;
+    if ((rc = gemm(c, VP_PROF_GEMM_FINAL, vp::EPI_HEATMAP, c->d2, c->w_fin, c->b_fin, c->hm, nullptr, n * 3072, c->Kp, 256, 0))) return rc;
+    return VP_OK;
+}
+
+int decode_chunk(vp_ctx* c, const int32_t* d_wh, float* d_out, int n) {
+    LAUNCH(c, VP_PROF_DECODE, 0.0, 4.0 * n * c->Kp * 3072.0 + 12.0 * n * c->Kp,
+           vp::decode_launch(c->hm, d_wh, d_out, n, c->Kp, c->stream));
+    return VP_OK;
+}
+
+size_t crop_bytes(int fmt) { return (size_t)3 * 256 * 192 * (fmt == VP_INPUT_F32_NCHW ? 4 : 1); }
+
+int check_ready(vp_ctx* c, int fmt, int n, const void* p0, const void* p1) {
+    if (!c) return VP_ERR_INVALID;
+    if (!c->loaded) return fail(c, VP_ERR_STATE, "weights not loaded: call vp_load_weights first");
+    if (fmt != VP_INPUT_F32_NCHW && fmt != VP_INPUT_U8_NHWC) return fail(c, VP_ERR_INVALID, "unknown input_format");
+    if (n < 0 || (n > 0 && (!p0 || !p1))) return fail(c, VP_ERR_INVALID, "null buffer or negative batch");
+    hipError_t e = hipSetDevice(c->cfg.device_id);
+    if (e != hipSuccess) return fail(c, VP_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(e));
+    return VP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int vp_abi_version(void) { return VP_ABI_VERSION; }
+
+int vp_create(vp_handle* out, const vp_config* cfg) {
+    if (!out || !cfg) return fail(nullptr, VP_ERR_INVALID, "null argument");
+    *out = nullptr;
+    const int D = cfg->embed_dim, h = cfg->num_heads;
+    if (D <= 0 || h <= 0 || D % h != 0 || D % 128 != 0 || D > 1280)
+        return fail(nullptr, VP_ERR_INVALID, "embed_dim must be a multiple of 128 (<= 1280) and divisible by num_heads");
+    const int hd = D / h;
+    if (hd != 32 && hd != 64 && hd != 80) return fail(nullptr, VP_ERR_INVALID, "head_dim must be 32, 64 or 80");
+    if (cfg->depth <= 0 || cfg->num_keypoints <= 0 || cfg->num_keypoints > 1024 || cfg->max_batch <= 0)
+        return fail(nullptr, VP_ERR_INVALID, "depth, num_keypoints and max_batch must be positive");
+    if (cfg->dtype != VP_DTYPE_F16 && cfg->dtype != VP_DTYPE_BF16) return fail(nullptr, VP_ERR_INVALID, "unknown dtype");
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+        return fail(nullptr, VP_ERR_HIP, std::string("no HIP device available (this library has no CPU fallback): ") +
+                                             (e != hipSuccess ? hipGetErrorString(e) : "device count 0"));
+    if (cfg->device_id < 0 || cfg->device_id >= ndev) return fail(nullptr, VP_ERR_INVALID, "device_id out of range");
+    vp_ctx* c = new vp_ctx();
+    c->cfg = *cfg;
+    c->D = D; c->L = cfg->depth; c->heads = h; c->Kp = cfg->num_keypoints;
+    c->dtype = cfg->dtype == VP_DTYPE_F16 ? vp::DT_F16 : vp::DT_BF16;
+    c->maxb = cfg->max_batch;
+    auto bail = [&](int rc) { g_create_error = c->err; vp_destroy(c); return rc; };
+    if ((e = hipSetDevice(cfg->device_id)) != hipSuccess) { c->err = hipGetErrorString(e); return bail(VP_ERR_HIP); }
+    if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) { c->err = hipGetErrorString(e); return bail(VP_ERR_HIP); }
+    const size_t B = (size_t)c->maxb, M = B * 192;
+    int rc = 0;
+    void* stage = nullptr;
+    if ((rc = dalloc(c, (char**)&stage, B * crop_bytes(VP_INPUT_F32_NCHW)))) return bail(rc);
+    c->in_stage = stage;
+    if ((rc = dalloc(c, &c->wh_stage, B * 2))) return bail(rc);
+    if ((rc = dalloc(c, &c->x, M * D))) return bail(rc);
+    if ((rc = dalloc(c, &c->y, M * D))) return bail(rc);
+    if ((rc = dalloc(c, &c->qkv, M * 3 * D))) return bail(rc);
+    if ((rc = dalloc(c, &c->hid, M * 4 * D))) return bail(rc);
+    if ((rc = dalloc(c, &c->d1, B * 768 * 256))) return bail(rc);
+    if ((rc = dalloc(c, &c->d2, B * 3072 * 256))) return bail(rc);
+    if ((rc = dalloc(c, &c->hm, B * c->Kp * 3072))) return bail(rc);
+    if ((rc = dalloc(c, &c->kp, B * c->Kp * 3))) return bail(rc);
+    if ((rc = dalloc(c, &c->zero, (size_t)256))) return bail(rc);
+    if (hipMemset(c->zero, 0, 512) != hipSuccess) { c->err = "hipMemset"; return bail(VP_ERR_HIP); }
+    *out = c;
+    return VP_OK;
+}
+
+int vp_load_weights(vp_handle c, const vp_tensor_desc* tensors, int32_t n_tensors) {
+    if (!c || !tensors || n_tensors <= 0) return fail(c, VP_ERR_INVALID, "null argument");
+    if (c->loaded) return fail(c, VP_ERR_STATE, "weights already loaded on this handle");
+    HIPCHK(c, hipSetDevice(c->cfg.device_id));
+    Lookup lk;
+    lk.c = c;
+    for (int i = 0; i < n_tensors; ++i)
+        if (tensors[i].name) lk.map[tensors[i].name] = &tensors[i];
+    const int D = c->D;
+    const size_t DD = (size_t)D * D;
+    int rc;
+    const float *p, *q;
+    // patch embed + positional embedding (vit.py:222, :382): aux[t] = pos[1+t] + pos[0] + conv bias
+    if ((rc = lk.get("backbone.patch_embed.proj.weight", (int64_t)D * 768, &p))) return rc;
+    if ((rc = upload_mat(c, &c->w_patch, p, D, 768, pad128(D)))) return rc;
+    if ((rc = lk.get("backbone.pos_embed", (int64_t)193 * D, &p))) return rc;
+    if ((rc = lk.get("backbone.patch_embed.proj.bias", D, &q))) return rc;
+    {
+        std::vector<float> pos((size_t)192 * D);
+        for (int t = 0; t < 192; ++t)
+            for (int d = 0; d < D; ++d) pos[(size_t)t * D + d] = (p[(size_t)(1 + t) * D + d] + p[d]) + q[d];
+        if ((rc = upload_f32(c, &c->pos, pos.data(), pos.size()))) return rc;
+    }
+    c->blocks.resize(c->L);
+    for (int l = 0; l < c->L; ++l) {
+        Block& b = c->blocks[l];
+        const std::string pre = "backbone.blocks." + std::to_string(l) + ".";
+        if ((rc = lk.get(pre + "norm1.weight", D, &p)) || (rc = upload_f32(c, &b.ln1_g, p, D))) return rc;
+        if ((rc = lk.get(pre + "norm1.bias", D, &p)) || (rc = upload_f32(c, &b.ln1_b, p, D))) return rc;
+        if ((rc = lk.get(pre + "norm2.weight", D, &p)) || (rc = upload_f32(c, &b.ln2_g, p, D))) return rc;
+        if ((rc = lk.get(pre + "norm2.bias", D, &p)) || (rc = upload_f32(c, &b.ln2_b, p, D))) return rc;
+        if ((rc = lk.get(pre + "attn.qkv.weight", (int64_t)3 * DD, &p)) || (rc = upload_mat(c, &b.w_qkv, p, 3 * (size_t)D, D, pad128(3 * (size_t)D)))) return rc;
+        if ((rc = lk.get(pre + "attn.qkv.bias", 3 * D, &p)) || (rc = upload_f32(c, &b.b_qkv, p, 3 * (size_t)D))) return rc;
+        if ((rc = lk.get(pre + "attn.proj.weight", (int64_t)DD, &p)) || (rc = upload_mat(c, &b.w_proj, p, D, D, pad128(D)))) return rc;
+        if ((rc = lk.get(pre + "attn.proj.bias", D, &p)) || (rc = upload_f32(c, &b.b_proj, p, D))) return rc;
+        if ((rc = lk.get(pre + "mlp.fc1.weight", (int64_t)4 * DD, &p)) || (rc = upload_mat(c, &b.w_fc1, p, 4 * (size_t)D, D, pad128(4 * (size_t)D)))) return rc;
+        if ((rc = lk.get(pre + "mlp.fc1.bias", 4 * D, &p)) || (rc = upload_f32(c, &b.b_fc1, p, 4 * (size_t)D))) return rc;
+        if ((rc = lk.get(pre + "mlp.fc2.weight", (int64_t)4 * DD, &p)) || (rc = upload_mat(c, &b.w_fc2, p, D, 4 * (size_t)D, pad128(D)))) return rc;
+        if ((rc = lk.get(pre + "mlp.fc2.bias", D, &p)) || (rc = upload_f32(c, &b.b_fc2, p, D))) return rc;
+    }
+    if ((rc = lk.get("backbone.last_norm.weight", D, &p)) || (rc = upload_f32(c, &c->lnf_g, p, D))) return rc;
+    if ((rc = lk.get("backbone.last_norm.bias", D, &p)) || (rc = upload_f32(c, &c->lnf_b, p, D))) return rc;
+    if ((rc = pack_deconv(c, lk, 0, D, &c->w_d1, &c->b_d1))) return rc;
+    if ((rc = pack_deconv(c, lk, 3, 256, &c->w_d2, &c->b_d2))) return rc;
+    if ((rc = lk.get("keypoint_head.final_layer.weight", (int64_t)c->Kp * 256, &p)) ||
+        (rc = upload_mat(c, &c->w_fin, p, c->Kp, 256, pad128(c->Kp)))) return rc;
+    if ((rc = lk.get("keypoint_head.final_layer.bias", c->Kp, &p)) || (rc = upload_f32(c, &c->b_fin, p, c->Kp, pad128(c->Kp)))) return rc;
+    {
+        std::vector<float> z(pad128(4 * (size_t)D), 0.f);
+        if ((rc = upload_f32(c, &c->b_zero, z.data(), z.size()))) return rc;
+    }
+    HIPCHK(c, hipDeviceSynchronize());
+    c->loaded = true;
+    return VP_OK;
+}
+
+int vp_infer_device(vp_handle c, const void* d_crops, int32_t fmt, int32_t n, const int32_t* d_org_wh, float* d_out, int32_t sync) {
+    int rc = check_ready(c, fmt, n, d_crops, d_out);
+    if (rc) return rc;
+    for (int off = 0; off < n; off += c->maxb) {
+        const int nb = (n - off < c->maxb) ? n - off : c->maxb;
+        const char* src = (const char*)d_crops + (size_t)off * crop_bytes(fmt);
+        if ((rc = forward_chunk(c, src, fmt, nb, false))) return rc;
+        if ((rc = decode_chunk(c, d_org_wh ? d_org_wh + 2 * (size_t)off : nullptr, d_out + (size_t)off * c->Kp * 3, nb))) return rc;
+    }
+    if (sync) HIPCHK(c, hipStreamSynchronize(c->stream));
+    return VP_OK;
+}
+
+int vp_infer(vp_handle c, const void* crops, int32_t fmt, int32_t n, const int32_t* org_wh, float* out) {
+    int rc = check_ready(c, fmt, n, crops, out);
+    if (rc) return rc;
+    for (int off = 0; off < n; off += c->maxb) {
+        const int nb = (n - off < c->maxb) ? n - off : c->maxb;
+        const char* src = (const char*)crops + (size_t)off * crop_bytes(fmt);
+        HIPCHK(c, hipMemcpyAsync(c->in_stage, src, (size_t)nb * crop_bytes(fmt), hipMemcpyHostToDevice, c->stream));
+        if (org_wh) HIPCHK(c, hipMemcpyAsync(c->wh_stage, org_wh + 2 * (size_t)off, (size_t)nb * 8, hipMemcpyHostToDevice, c->stream));
+        if ((rc = forward_chunk(c, c->in_stage, fmt, nb, false))) return rc;
+        if ((rc = decode_chunk(c, org_wh ? c->wh_stage : nullptr, c->kp, nb))) return rc;
+        HIPCHK(c, hipMemcpyAsync(out + (size_t)off * c->Kp * 3, c->kp, (size_t)nb * c->Kp * 12, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    return VP_OK;
+}
+
+int vp_infer_heatmaps(vp_handle c, const void* crops, int32_t fmt, int32_t n, float* heatmaps) {
+    int rc = check_ready(c, fmt, n, crops, heatmaps);
+    if (rc) return rc;
+    for (int off = 0; off < n; off += c->maxb) {
+        const int nb = (n - off < c->maxb) ? n - off : c->maxb;
+        HIPCHK(c, hipMemcpyAsync(c->in_stage, (const char*)crops + (size_t)off * crop_bytes(fmt), (size_t)nb * crop_bytes(fmt), hipMemcpyHostToDevice, c->stream));
+        if ((rc = forward_chunk(c, c->in_stage, fmt, nb, false))) return rc;
+        HIPCHK(c, hipMemcpyAsync(heatmaps + (size_t)off * c->Kp * 3072, c->hm, (size_t)nb * c->Kp * 3072 * 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    return VP_OK;
+}
+
+int vp_infer_tokens(vp_handle c, const void* crops, int32_t fmt, int32_t n, float* tokens) {
+    int rc = check_ready(c, fmt, n, crops, tokens);
+    if (rc) return rc;
+    if (!c->tok && (rc = dalloc(c, &c->tok, (size_t)c->maxb * 192 * c->D))) return rc;
+    for (int off = 0; off < n; off += c->maxb) {
+        const int nb = (n - off < c->maxb) ? n - off : c->maxb;
+        HIPCHK(c, hipMemcpyAsync(c->in_stage, (const char*)crops + (size_t)off * crop_bytes(fmt), (size_t)nb * crop_bytes(fmt), hipMemcpyHostToDevice, c->stream));
+        if ((rc = forward_chunk(c, c->in_stage, fmt, nb, true))) return rc;
+        HIPCHK(c, hipMemcpyAsync(tokens + (size_t)off * 192 * c->D, c->tok, (size_t)nb * 192 * c->D * 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    return VP_OK;
+}
+
+int vp_decode_only(int32_t device_id, const float* heatmaps, int32_t n, int32_t k, const int32_t* org_wh, float* out) {
+    if (!heatmaps || !out || n <= 0 || k <= 0) return fail(nullptr, VP_ERR_INVALID, "bad argument");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(nullptr, VP_ERR_HIP, "no HIP device available (no CPU fallback)");
+    if (device_id < 0 || device_id >= ndev) return fail(nullptr, VP_ERR_INVALID, "device_id out of range");
+    vp_ctx* c = nullptr;   // errors below are reported through the create-error slot
+    HIPCHK(c, hipSetDevice(device_id));
+    float *d_hm = nullptr, *d_out = nullptr;
+    int32_t* d_wh = nullptr;
+    const size_t hb = (size_t)n * k * 3072 * 4, ob = (size_t)n * k * 12;
+    HIPCHK(c, hipMalloc((void**)&d_hm, hb));
+    HIPCHK(c, hipMalloc((void**)&d_out, ob));
+    int rc = VP_OK;
+    hipError_t e = hipMemcpy(d_hm, heatmaps, hb, hipMemcpyHostToDevice);
+    if (e == hipSuccess && org_wh) {
+        e = hipMalloc((void**)&d_wh, (size_t)n * 8);
+        if (e == hipSuccess) e = hipMemcpy(d_wh, org_wh, (size_t)n * 8, hipMemcpyHostToDevice);
+    }
+    if (e == hipSuccess) e = vp::decode_launch(d_hm, d_wh, d_out, n, k, nullptr);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipMemcpy(out, d_out, ob, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) rc = fail(nullptr, VP_ERR_HIP, std::string("vp_decode_only: ") + hipGetErrorString(e));
+    hipFree(d_hm); hipFree(d_out); if (d_wh) hipFree(d_wh);
+    return rc;
+}
+
+void* vp_stream(vp_handle c) { return c ? (void*)c->stream : nullptr; }
+
+int vp_synchronize(vp_handle c) {
+    if (!c) return VP_ERR_INVALID;
+    HIPCHK(c, hipSetDevice(c->cfg.device_id));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return VP_OK;
+}
+
+int vp_set_profiling(vp_handle c, int32_t enable) {
+    if (!c) return VP_ERR_INVALID;
+    c->prof = (uint32_t)enable;   // bitmask over VP_PROF_* families (-1 = all)
+    return VP_OK;
+}
+
+int vp_reset_profile(vp_handle c) {
+    if (!c) return VP_ERR_INVALID;
+    hipStreamSynchronize(c->stream);
+    prof_collect(c);
+    std::memset(&c->acc, 0, sizeof(c->acc));
+    return VP_OK;
+}
+
+int vp_get_profile(vp_handle c, vp_profile* out) {
+    if (!c || !out) return VP_ERR_INVALID;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    prof_collect(c);
+    *out = c->acc;
+    return VP_OK;
+}
+
+int vp_destroy(vp_handle c) {
+    if (!c) return VP_OK;
+    hipSetDevice(c->cfg.device_id);
+    if (c->stream) hipStreamSynchronize(c->stream);
+    for (auto& e : c->evs) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
+    for (auto& p : c->ev_pool) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
+    for (void* p : c->allocs) hipFree(p);
+    if (c->stream) hipStreamDestroy(c->stream);
+    delete c;
+    return VP_OK;
+}
+
+const char* vp_last_error(vp_handle c) { return c ? c->err.c_str() : g_create_error.c_str(); }
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------
+// Debug / parity taps: run ONE kernel on host fp32 data (operands are rounded to
+// `dtype` exactly as the production packer / producers do).  Used by tests/ only.
+// ---------------------------------------------------------------------------
+namespace {
+vp_ctx* dbg_ctx(int device, int dtype) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) {
+        g_create_error = "no HIP device available (no CPU fallback)";
+        return nullptr;
+    }
+    if (hipSetDevice(device) != hipSuccess) return nullptr;
+    vp_ctx* c = new vp_ctx();
+    c->cfg.device_id = device;
+    c->dtype = dtype == VP_DTYPE_F16 ? vp::DT_F16 : vp::DT_BF16;
+    return c;
+}
+int dbg_finish(vp_ctx* c, int rc) {
+    if (rc) g_create_error = c->err;
+    vp_destroy(c);
+    return rc;
+}
+// device 16-bit -> host fp32
+int download16(vp_ctx* c, const uint16_t* d, float* out, size_t n) {
+    std::vector<uint16_t> t(n);
+    HIPCHK(c, hipMemcpy(t.data(), d, n * 2, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < n; ++i) {
+        if (c->dtype == vp::DT_BF16) {
+            uint32_t u = (uint32_t)t[i] << 16;
+            std::memcpy(&out[i], &u, 4);
+        } else {
+            const uint32_t h = t[i], sign = (h & 0x8000u) << 16, e = (h >> 10) & 0x1f, m = h & 0x3ff;
+            uint32_t u;
+            if (e == 0) {
+                if (m == 0) u = sign;
+                else { int sh = 0; uint32_t mm = m; while (!(mm & 0x400)) { mm <<= 1; ++sh; }
+                       u = sign | ((uint32_t)(113 - sh) << 23) | ((mm & 0x3ff) << 13); }
+            } else if (e == 31) u = sign | 0x7f800000u | (m << 13);
+            else u = sign | ((e + 112) << 23) | (m << 13);
+            std::memcpy(&out[i], &u, 4);
+        }
+    }
+    return VP_OK;
+}
+}  // namespace
+
+extern "C" {
+
+// out = epilogue(A[M,K] . W[N,K]^T): epi 0 bias->16bit, 1 bias+gelu->16bit, 2 bias+aux[M,N]->fp32, 3 aux[m%192]->fp32
+VP_API int vp_dbg_gemm(int32_t device, int32_t dtype, int32_t epi, int32_t M, int32_t N, int32_t K, const float* A,
+                       const float* W, const float* bias, const float* aux, float* out) {
+    if (epi < 0 || epi > 3 || M <= 0 || N <= 0 || K <= 0 || K % 64) return fail(nullptr, VP_ERR_INVALID, "bad gemm test shape");
+    vp_ctx* c = dbg_ctx(device, dtype);
+    if (!c) return VP_ERR_HIP;
+    uint16_t *dA, *dW, *dO16 = nullptr;
+    float *dB, *dAux = nullptr, *dO32 = nullptr;
+    int rc;
+    const size_t MN = (size_t)M * N;
+    if ((rc = upload_mat(c, &dA, A, M, K, M))) return dbg_finish(c, rc);
+    if ((rc = upload_mat(c, &dW, W, N, K, pad128(N)))) return dbg_finish(c, rc);
+    if ((rc = upload_f32(c, &dB, bias, N, pad128(N)))) return dbg_finish(c, rc);
+    if (epi >= 2) {
+        if ((rc = upload_f32(c, &dAux, aux, epi == 2 ? MN : (size_t)192 * N))) return dbg_finish(c, rc);
+        if ((rc = dalloc(c, &dO32, MN))) return dbg_finish(c, rc);
+    } else if ((rc = dalloc(c, &dO16, MN))) return dbg_finish(c, rc);
+    if ((rc = dalloc(c, &c->zero, (size_t)256))) return dbg_finish(c, rc);
+    rc = gemm(c, 0, epi, dA, dW, dB, epi >= 2 ? (void*)dO32 : (void*)dO16, dAux, M, N, K, N);
+    if (!rc && hipDeviceSynchronize() != hipSuccess) rc = fail(c, VP_ERR_HIP, "gemm kernel failed");
+    if (!rc) {
+        if (epi >= 2) { if (hipMemcpy(out, dO32, MN * 4, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(c, VP_ERR_HIP, "D2H"); }
+        else rc = download16(c, dO16, out, MN);
+    }
+    return dbg_finish(c, rc);
+}
+
+// qkv [B*192, 3*D] fp32 -> out [B*192, D] fp32 (attention core, vit.py:167-176)
+VP_API int vp_dbg_attention(int32_t device, int32_t dtype, int32_t B, int32_t D, int32_t heads, const float* qkv, float* out) {
+    vp_ctx* c = dbg_ctx(device, dtype);
+    if (!c) return VP_ERR_HIP;
+    uint16_t *dq, *dout;
+    int rc;
+    const size_t M = (size_t)B * 192;
+    if ((rc = upload_mat(c, &dq, qkv, M, 3 * (size_t)D, M))) return dbg_finish(c, rc);
+    if ((rc = dalloc(c, &dout, M * D))) return dbg_finish(c, rc);
+    hipError_t e = vp::attention_launch(c->dtype, dq, dout, B, D, heads, nullptr);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e != hipSuccess) return dbg_finish(c, fail(c, VP_ERR_HIP, std::string("attention: ") + hipGetErrorString(e)));
+    return dbg_finish(c, download16(c, dout, out, M * D));
+}
+
+// LayerNorm(eps 1e-6): x [M,D] fp32 -> out16 (as fp32) [M,D] and out32 [M,D]
+VP_API int vp_dbg_layernorm(int32_t device, int32_t dtype, int32_t M, int32_t D, const float* x, const float* gamma,
+                            const float* beta, float* out16, float* out32) {
+    vp_ctx* c = dbg_ctx(device, dtype);
+    if (!c) return VP_ERR_HIP;
+    float *dx, *dg, *db, *d32;
+    uint16_t* d16;
+    int rc;
+    const size_t MD = (size_t)M * D;
+    if ((rc = upload_f32(c, &dx, x, MD)) || (rc = upload_f32(c, &dg, gamma, D)) || (rc = upload_f32(c, &db, beta, D)) ||
+        (rc = dalloc(c, &d32, MD)) || (rc = dalloc(c, &d16, MD))) return dbg_finish(c, rc);
+    hipError_t e = vp::layernorm_launch(c->dtype, dx, dg, db, d16, d32, M, D, nullptr);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipMemcpy(out32, d32, MD * 4, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return dbg_finish(c, fail(c, VP_ERR_HIP, std::string("layernorm: ") + hipGetErrorString(e)));
+    return dbg_finish(c, download16(c, d16, out16, MD));
+}
+
+// ConvTranspose2d(Cin,256,4,2,1,bias=False)+BN(eval)+ReLU on NHWC x [B,Hin,Win,Cin] fp32 -> NHWC [B,2Hin,2Win,256] fp32.
+// tensors = {"keypoint_head.deconv_layers.0.weight", ".1.weight", ".1.bias", ".1.running_mean", ".1.running_var"}
+VP_API int vp_dbg_deconv(int32_t device, int32_t dtype, int32_t B, int32_t Hin, int32_t Win, int32_t Cin, const float* x,
+                         const vp_tensor_desc* tensors, int32_t n_tensors, float* out) {
+    vp_ctx* c = dbg_ctx(device, dtype);
+    if (!c) return VP_ERR_HIP;
+    Lookup lk;
+    lk.c = c;
+    for (int i = 0; i < n_tensors; ++i) lk.map[tensors[i].name] = &tensors[i];
+    uint16_t *dx, *dw, *dout;
+    float* db;
+    int rc;
+    const size_t Min = (size_t)B * Hin * Win;
+    if ((rc = pack_deconv(c, lk, 0, Cin, &dw, &db))) return dbg_finish(c, rc);
+    if ((rc = upload_mat(c, &dx, x, Min, Cin, Min))) return dbg_finish(c, rc);
+    if ((rc = dalloc(c, &dout, Min * 4 * 256))) return dbg_finish(c, rc);
+    if ((rc = dalloc(c, &c->zero, (size_t)256))) return dbg_finish(c, rc);
+    if (hipMemset(c->zero, 0, 512) != hipSuccess) return dbg_finish(c, fail(c, VP_ERR_HIP, "memset"));
+    rc = gemm(c, 0, vp::EPI_DECONV, dx, dw, db, dout, nullptr, (int)Min, 256, 4 * Cin, 256, Hin, Win, Cin);
+    if (!rc && hipDeviceSynchronize() != hipSuccess) rc = fail(c, VP_ERR_HIP, "deconv kernel failed");
+    if (!rc) rc = download16(c, dout, out, Min * 4 * 256);
+    return dbg_finish(c, rc);
+}
+
+}  // extern "C"

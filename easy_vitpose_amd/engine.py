@@ -1,0 +1,159 @@
+"""Python host object over the C ABI: one ``VitPoseHip`` = one model on one GPU.
+
+The C library owns the weights, workspaces and its HIP stream; numpy / torch are
+only used to hand it pointers.  There is no CPU implementation behind this class.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _capi as capi
+from .configs import HM_H, HM_W, IMG_H, IMG_W, ModelShape
+
+
+def _as_f32_numpy(v) -> np.ndarray:
+    if hasattr(v, 'detach'):  # torch tensor
+        v = v.detach().cpu().numpy()
+    return np.ascontiguousarray(np.asarray(v), dtype=np.float32)
+
+
+class VitPoseHip:
+    """ViTPose (backbone + head + decode) on one MI355X through libvitpose_hip.so."""
+
+    def __init__(self, shape: ModelShape, state_dict, dtype: str = 'fp16', device_id: int = 0, max_batch: int = 64):
+        self.lib = capi.load_library()
+        self.shape = shape
+        self.dtype = dtype
+        self.device_id = int(device_id)
+        self.max_batch = int(max_batch)
+        self.K = shape.num_keypoints
+        cfg = capi.vp_config(shape.embed_dim, shape.depth, shape.num_heads, shape.num_keypoints,
+                             capi.DTYPES[dtype], self.device_id, self.max_batch)
+        h = C.c_void_p()
+        capi.check(self.lib.vp_create(C.byref(h), C.byref(cfg)))
+        self._h = h
+        try:
+            self._load(state_dict)
+        except Exception:
+            self.close()
+            raise
+
+    # -------------------------------------------------------------- weights
+    def _load(self, state_dict):
+        sd = state_dict['state_dict'] if 'state_dict' in state_dict else state_dict  # inference.py:163-166
+        keep, descs = [], []
+        for name, v in sd.items():
+            if name.endswith('num_batches_tracked'):
+                continue
+            a = _as_f32_numpy(v)
+            keep.append(a)
+            descs.append(capi.vp_tensor_desc(name.encode(), a.ctypes.data_as(C.POINTER(C.c_float)), a.size))
+        arr = (capi.vp_tensor_desc * len(descs))(*descs)
+        code = self.lib.vp_load_weights(self._h, arr, len(descs))
+        if code == capi.VP_ERR_MISSING_TENSOR:
+            raise KeyError(capi.last_error(self._h))      # load_state_dict's "Missing key(s)"
+        if code == capi.VP_ERR_SHAPE:
+            raise RuntimeError(capi.last_error(self._h))  # load_state_dict's "size mismatch"
+        capi.check(code, self._h)
+
+    # ------------------------------------------------------------ inference
+    @staticmethod
+    def _fmt(crops: np.ndarray):
+        if crops.dtype == np.uint8:
+            assert crops.ndim == 4 and crops.shape[1:] == (IMG_H, IMG_W, 3), \
+                f'uint8 crops must be [N,{IMG_H},{IMG_W},3], got {crops.shape}'
+            return capi.VP_INPUT_U8_NHWC
+        assert crops.dtype == np.float32 and crops.ndim == 4 and crops.shape[1:] == (3, IMG_H, IMG_W), \
+            f'float32 crops must be [N,3,{IMG_H},{IMG_W}], got {crops.dtype} {crops.shape}'
+        return capi.VP_INPUT_F32_NCHW
+
+    def infer(self, crops: np.ndarray, org_wh=None) -> np.ndarray:
+        """crops (uint8 NHWC raw, or float32 NCHW normalised) -> float32 [N, K, 3] (y, x, conf)."""
+        crops = np.ascontiguousarray(crops)
+        fmt = self._fmt(crops)
+        n = crops.shape[0]
+        out = np.empty((n, self.K, 3), dtype=np.float32)
+        if n == 0:
+            return out
+        wh = None if org_wh is None else np.ascontiguousarray(org_wh, dtype=np.int32).reshape(n, 2)
+        capi.check(self.lib.vp_infer(self._h, crops.ctypes.data, fmt, n,
+                                     None if wh is None else wh.ctypes.data, out.ctypes.data), self._h)
+        return out
+
+    def infer_device(self, d_crops, d_out, org_wh=None, sync: bool = True):
+        """Device-resident torch tensors in/out (no copies); enqueued on the library's stream."""
+        import torch
+        assert d_crops.is_cuda and d_out.is_cuda and d_crops.is_contiguous() and d_out.is_contiguous()
+        fmt = capi.VP_INPUT_U8_NHWC if d_crops.dtype == torch.uint8 else capi.VP_INPUT_F32_NCHW
+        n = d_crops.shape[0]
+        assert d_out.dtype == torch.float32 and d_out.numel() == n * self.K * 3
+        whp = None
+        if org_wh is not None:
+            assert org_wh.is_cuda and org_wh.dtype == torch.int32 and org_wh.numel() == 2 * n
+            whp = org_wh.data_ptr()
+        capi.check(self.lib.vp_infer_device(self._h, d_crops.data_ptr(), fmt, n, whp, d_out.data_ptr(), int(sync)), self._h)
+        return d_out
+
+    def heatmaps(self, crops: np.ndarray) -> np.ndarray:
+        crops = np.ascontiguousarray(crops)
+        n = crops.shape[0]
+        out = np.empty((n, self.K, HM_H, HM_W), dtype=np.float32)
+        capi.check(self.lib.vp_infer_heatmaps(self._h, crops.ctypes.data, self._fmt(crops), n, out.ctypes.data), self._h)
+        return out
+
+    def tokens(self, crops: np.ndarray) -> np.ndarray:
+        crops = np.ascontiguousarray(crops)
+        n = crops.shape[0]
+        out = np.empty((n, 192, self.shape.embed_dim), dtype=np.float32)
+        capi.check(self.lib.vp_infer_tokens(self._h, crops.ctypes.data, self._fmt(crops), n, out.ctypes.data), self._h)
+        return out
+
+    # ------------------------------------------------------------ profiling
+    def set_profiling(self, families=True):
+        """True/False = all/none, or an iterable of family names from ``_capi.VP_PROF_NAMES``."""
+        if families is True:
+            mask = -1
+        elif not families:
+            mask = 0
+        else:
+            mask = 0
+            for f in families:
+                mask |= 1 << capi.VP_PROF_NAMES.index(f)
+        capi.check(self.lib.vp_set_profiling(self._h, mask), self._h)
+
+    def reset_profile(self):
+        capi.check(self.lib.vp_reset_profile(self._h), self._h)
+
+    def profile(self) -> dict:
+        p = capi.vp_profile()
+        capi.check(self.lib.vp_get_profile(self._h, C.byref(p)), self._h)
+        return {name: dict(ms=p.ms[i], flops=p.flops[i], bytes=p.bytes[i], launches=p.launches[i])
+                for i, name in enumerate(capi.VP_PROF_NAMES)}
+
+    def synchronize(self):
+        capi.check(self.lib.vp_synchronize(self._h), self._h)
+
+    def close(self):
+        if getattr(self, '_h', None):
+            self.lib.vp_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def decode_heatmaps(heatmaps: np.ndarray, org_wh=None, device_id: int = 0) -> np.ndarray:
+    """GPU decode of host heatmaps [N,K,64,48] -> [N,K,3] (y, x, conf) (vp_decode_only)."""
+    lib = capi.load_library()
+    hm = np.ascontiguousarray(heatmaps, dtype=np.float32)
+    n, k, h, w = hm.shape
+    assert (h, w) == (HM_H, HM_W)
+    out = np.empty((n, k, 3), dtype=np.float32)
+    wh = None if org_wh is None else np.ascontiguousarray(org_wh, dtype=np.int32).reshape(n, 2)
+    capi.check(lib.vp_decode_only(device_id, hm.ctypes.data, n, k, None if wh is None else wh.ctypes.data, out.ctypes.data))
+    return out

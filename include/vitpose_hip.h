@@ -1,0 +1,173 @@
+/*
+ * vitpose_hip.h -- C ABI of the MI355X-native ViTPose hot path (libvitpose_hip.so).
+ *
+ * Drop-in boundary: the reference's backend slot `VitInference._inference`
+ * (easy_ViTPose/inference.py:207-219, assigned at :169-172, called at :268) whose
+ * existing implementations are `_inference_torch` (:320-328) and `_inference_onnx`
+ * (:330-337).  A backend takes one cropped+padded RGB crop, runs
+ *     pre_img (:314-318) -> ViTPose.forward (vit_models/model.py:23-24)
+ *             -> postprocess (:187-205)
+ * and returns float32 [1, K, 3] = (y, x, conf) in crop pixels.  This library is
+ * the batched form of exactly that call: N crops in, [N, K, 3] out.
+ *
+ * Plain C: opaque handle, plain pointers and sizes, int status codes.  No torch
+ * types, no C++ types.  All entry points are thread-compatible, not thread-safe:
+ * calls on one handle must be serialised by the caller (the reference's
+ * VitInference is single-threaded and stateful too, inference.py:112-116).
+ * Nothing here falls back to a CPU implementation: without a gfx950 device every
+ * compute entry point returns VP_ERR_HIP.
+ */
+#ifndef VITPOSE_HIP_H
+#define VITPOSE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VP_ABI_VERSION 1
+#define VP_API __attribute__((visibility("default")))
+
+/* status codes (0 = ok).  The Python host maps them onto the exception types the
+ * reference raises at the same places (AssertionError / ValueError / KeyError,
+ * easy_ViTPose/inference.py:91-92,127-128,138-144; vit_utils/util.py:33). */
+enum {
+    VP_OK = 0,
+    VP_ERR_INVALID = 1,        /* bad argument / unsupported shape          */
+    VP_ERR_HIP = 2,            /* HIP runtime error, no device, OOM         */
+    VP_ERR_STATE = 3,          /* weights not loaded yet, handle destroyed  */
+    VP_ERR_MISSING_TENSOR = 4, /* state-dict key absent (load_state_dict KeyError analogue) */
+    VP_ERR_SHAPE = 5           /* state-dict tensor has the wrong size      */
+};
+
+/* arithmetic type of the GEMM/attention operands (accumulation is always fp32,
+ * residual stream / LayerNorm / softmax statistics / heatmaps / decode are fp32) */
+enum { VP_DTYPE_F16 = 0, VP_DTYPE_BF16 = 1 };
+
+/* layout of the crop batch handed to vp_infer* */
+enum {
+    VP_INPUT_F32_NCHW = 0, /* float32 [N,3,256,192], already normalised = output of pre_img (inference.py:314-318) */
+    VP_INPUT_U8_NHWC = 1   /* uint8   [N,256,192,3] RGB crops; (x/255-mean)/std (inference.py:32-33,316-317) is applied on device */
+};
+
+typedef struct vp_ctx* vp_handle;
+
+/* Model shape = one row of configs/ViTPose_common.py:65-195 + the dataset's
+ * out_channels (configs/ViTPose_<dataset>.py).  Input is fixed at 256x192,
+ * heatmaps at 64x48 (ViTPose_common.py:29-31). */
+typedef struct vp_config {
+    int32_t embed_dim;     /* 384 / 768 / 1024 / 1280 */
+    int32_t depth;         /* 12 / 12 / 24 / 32       */
+    int32_t num_heads;     /* 12 / 12 / 16 / 16  (head_dim must be 32, 64 or 80) */
+    int32_t num_keypoints; /* 17 / 25 / 133 / ...      */
+    int32_t dtype;         /* VP_DTYPE_*              */
+    int32_t device_id;     /* HIP device ordinal      */
+    int32_t max_batch;     /* workspace is sized for this many crops; larger N is processed in chunks */
+} vp_config;
+
+/* One tensor of the checkpoint, host float32, named exactly as in the reference's
+ * state dict (`backbone.pos_embed`, `backbone.blocks.3.attn.qkv.weight`,
+ * `keypoint_head.deconv_layers.1.running_var`, ... ; schema in SURVEY.md 8a,
+ * loaded by the reference at easy_ViTPose/inference.py:162-166). */
+typedef struct vp_tensor_desc {
+    const char* name;
+    const float* data;
+    int64_t numel;
+} vp_tensor_desc;
+
+/* Per-kernel-family timing collected with HIP events on the handle's stream. */
+#define VP_PROF_GEMM_PROJ 0  /* proj/fc2 GEMM  (bias + residual -> fp32)  -- dominant kernel */
+#define VP_PROF_GEMM_FC1 1   /* fc1 GEMM (bias + GELU)                     */
+#define VP_PROF_GEMM_QKV 2   /* qkv GEMM (bias)                            */
+#define VP_PROF_GEMM_PATCH 3 /* patch-embed GEMM (bias + pos)              */
+#define VP_PROF_GEMM_DECONV 4
+#define VP_PROF_GEMM_FINAL 5
+#define VP_PROF_ATTN 6
+#define VP_PROF_LAYERNORM 7
+#define VP_PROF_IM2COL 8
+#define VP_PROF_DECODE 9
+#define VP_PROF_COUNT 10
+
+typedef struct vp_profile {
+    double ms[VP_PROF_COUNT];      /* summed kernel time since the last reset  */
+    double flops[VP_PROF_COUNT];   /* summed algorithmic FLOPs (2*M*N*K)       */
+    double bytes[VP_PROF_COUNT];   /* summed algorithmic HBM bytes              */
+    int64_t launches[VP_PROF_COUNT];
+} vp_profile;
+
+VP_API int vp_abi_version(void);
+
+/* Create a context on cfg->device_id: stream, workspaces.  Replaces the model
+ * construction `ViTPose(model_cfg)` + `.to(device)` (inference.py:156-167). */
+VP_API int vp_create(vp_handle* out, const vp_config* cfg);
+
+/* Upload a checkpoint: folds BatchNorm (eval, eps 1e-5) into the deconv weights,
+ * pre-adds pos_embed[:,1:]+pos_embed[:,:1] (vit.py:382), re-tiles the transposed-conv
+ * weights into 4 output-parity GEMM operands, converts matrices to cfg.dtype.
+ * Replaces `load_state_dict` (inference.py:162-166).  Missing key ->
+ * VP_ERR_MISSING_TENSOR, wrong numel -> VP_ERR_SHAPE. */
+VP_API int vp_load_weights(vp_handle h, const vp_tensor_desc* tensors, int32_t n_tensors);
+
+/* The hot path on host buffers: H2D crops, model, decode, D2H keypoints; returns
+ * when `out` is complete.  Batched replacement of `_inference_torch`
+ * (inference.py:320-328).  org_wh = N x (org_w, org_h) int32 of each crop before
+ * pre_img's resize (NULL = 192x256 for all); out = float32 [N, K, 3] (y, x, conf). */
+VP_API int vp_infer(vp_handle h, const void* crops, int32_t input_format, int32_t n,
+             const int32_t* org_wh, float* out);
+
+/* Same with device-resident buffers (e.g. torch tensors' data_ptr()); enqueued on
+ * the handle's stream, returns after the stream has been synchronised when
+ * `sync` != 0.  d_org_wh may be NULL. */
+VP_API int vp_infer_device(vp_handle h, const void* d_crops, int32_t input_format, int32_t n,
+                    const int32_t* d_org_wh, float* d_out, int32_t sync);
+
+/* Parity/debug taps.  Heatmaps = ViTPose.forward output, float32 [N, K, 64, 48]. */
+VP_API int vp_infer_heatmaps(vp_handle h, const void* crops, int32_t input_format, int32_t n, float* heatmaps);
+/* Backbone output after last_norm (vit.py:387), float32 [N, 192, D]. */
+VP_API int vp_infer_tokens(vp_handle h, const void* crops, int32_t input_format, int32_t n, float* tokens);
+
+/* Decode alone: keypoints_from_heatmaps(unbiased=True, use_udp=True) + postprocess
+ * (vit_utils/top_down_eval.py:493-641, easy_ViTPose/inference.py:187-205), one crop
+ * at a time semantics.  heatmaps float32 [N, K, 64, 48] on the host. */
+VP_API int vp_decode_only(int32_t device_id, const float* heatmaps, int32_t n, int32_t k,
+                   const int32_t* org_wh, float* out);
+
+/* HIP stream of the handle (a hipStream_t), for callers that order their own work against it. */
+VP_API void* vp_stream(vp_handle h);
+VP_API int vp_synchronize(vp_handle h);
+
+/* HIP-event timing per kernel family: family_mask bit f (1 << VP_PROF_*) turns timing of
+ * family f on (two event records around each of its launches); -1 = all, 0 = off. */
+VP_API int vp_set_profiling(vp_handle h, int32_t family_mask);
+VP_API int vp_reset_profile(vp_handle h);
+VP_API int vp_get_profile(vp_handle h, vp_profile* out);
+
+VP_API int vp_destroy(vp_handle h);
+
+/* Last error text of this handle (or of the failed vp_create when h == NULL).
+ * The pointer stays valid until the next call on the same handle. */
+VP_API const char* vp_last_error(vp_handle h);
+
+/* ---- parity taps (used by tests/ only): run ONE kernel on host fp32 data; operands are
+ * rounded to `dtype` exactly as the production packer / producing kernels round them. ---- */
+/* out[M,N] = epilogue(A[M,K] . W[N,K]^T); epi: 0 = +bias (nn.Linear, vit.py:166), 1 = gelu(+bias)
+ * (Mlp fc1+act, vit.py:137-138), 2 = +bias +aux[M,N] (residual add, vit.py:203-204),
+ * 3 = +aux[m % 192] (patch embed + pos, vit.py:382).  K % 64 == 0. */
+VP_API int vp_dbg_gemm(int32_t device_id, int32_t dtype, int32_t epi, int32_t M, int32_t N, int32_t K,
+                       const float* A, const float* W, const float* bias, const float* aux, float* out);
+/* qkv [B*192, 3*D] -> attention core output [B*192, D]  (vit.py:167-176) */
+VP_API int vp_dbg_attention(int32_t device_id, int32_t dtype, int32_t B, int32_t D, int32_t heads,
+                            const float* qkv, float* out);
+/* LayerNorm(eps=1e-6) of x [M,D]: out16 = result rounded to dtype (returned as fp32), out32 = fp32 result */
+VP_API int vp_dbg_layernorm(int32_t device_id, int32_t dtype, int32_t M, int32_t D, const float* x,
+                            const float* gamma, const float* beta, float* out16, float* out32);
+/* ConvTranspose2d(Cin,256,4,2,1)+BN(eval)+ReLU (topdown_heatmap_simple_head.py:303-319) on NHWC
+ * x [B,Hin,Win,Cin] -> NHWC [B,2Hin,2Win,256]; tensors named keypoint_head.deconv_layers.{0,1}.* */
+VP_API int vp_dbg_deconv(int32_t device_id, int32_t dtype, int32_t B, int32_t Hin, int32_t Win, int32_t Cin,
+                         const float* x, const vp_tensor_desc* tensors, int32_t n_tensors, float* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VITPOSE_HIP_H */

@@ -1,0 +1,40 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, 'tests'), os.path.join(ROOT, 'tests', 'golden')):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+
+
+def _has_gpu() -> bool:
+    try:
+        import torch
+        return torch.cuda.is_available()
+    except Exception:
+        return False
+
+
+HAS_GPU = _has_gpu()
+
+
+def pytest_collection_modifyitems(config, items):
+    # gpu tests never silently pass on a CPU box: they are skipped (and the -m filter is
+    # what the drivers use); on a GPU box a missing extension must FAIL, not skip.
+    if HAS_GPU:
+        return
+    skip = pytest.mark.skip(reason='no GPU in this container (gpu-marked test)')
+    for it in items:
+        if 'gpu' in it.keywords:
+            it.add_marker(skip)
+
+
+@pytest.fixture(scope='session')
+def golden_dir():
+    return os.path.join(ROOT, 'tests', 'golden')

@@ -1,0 +1,57 @@
+"""Seeded input generators shared by the golden generator and the tests.
+
+Inputs are regenerated from seeds (bit-identical numpy PCG64 streams); only the
+reference's OUTPUTS are stored in the ``.npz`` fixtures next to this file.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+HM_H, HM_W = 64, 48
+
+
+def peaked_heatmaps(n: int, k: int, seed: int) -> np.ndarray:
+    """Heatmaps ``[n, k, 64, 48]`` float32 that look like a trained model's output:
+    gaussian blobs (sigma 2, amplitude 0.3..0.95) + N(0, 0.01) noise, with sub-pixel
+    centres.  Deliberate edge cases:
+
+    * joints k%6==1: centre within 0..2 px of a border / in a corner,
+    * joint (crop 1, k=0) and (crop 2, k=3): all values <= 0  (coords become -1),
+    * joint (crop 3, k=2): two exactly tied maxima (first index must win),
+    * joint (crop 4, k=5): flat constant positive map.
+    """
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:HM_H, 0:HM_W].astype(np.float32)
+    hm = np.empty((n, k, HM_H, HM_W), dtype=np.float32)
+    for i in range(n):
+        for j in range(k):
+            if j % 6 == 1:
+                side = int(rng.integers(0, 6))
+                cx = rng.uniform(0, 2) if side in (0, 4) else (HM_W - 1 - rng.uniform(0, 2) if side in (1, 5) else rng.uniform(0, HM_W - 1))
+                cy = rng.uniform(0, 2) if side in (2, 4) else (HM_H - 1 - rng.uniform(0, 2) if side in (3, 5) else rng.uniform(0, HM_H - 1))
+            else:
+                cx, cy = rng.uniform(3, HM_W - 4), rng.uniform(3, HM_H - 4)
+            amp = rng.uniform(0.3, 0.95)
+            g = amp * np.exp(-((xx - cx) ** 2 + (yy - cy) ** 2) / (2 * 2.0 ** 2))
+            hm[i, j] = g + rng.normal(0, 0.01, size=g.shape).astype(np.float32)
+    if n > 1:
+        hm[1, 0] = -np.abs(hm[1, 0]) - 0.01
+    if n > 2 and k > 3:
+        hm[2, 3] = -np.abs(hm[2, 3])
+        hm[2, 3, 10, 10] = 0.0          # max == 0 exactly -> still "<= 0"
+    if n > 3 and k > 2:
+        m = float(hm[3, 2].max()) + 0.05
+        hm[3, 2, 20, 30] = m
+        hm[3, 2, 40, 7] = m
+    if n > 4 and k > 5:
+        hm[4, 5] = 0.25
+    return hm
+
+
+def org_sizes(n: int, seed: int) -> np.ndarray:
+    """(org_w, org_h) per crop: crop 0 is the native 192x256, the rest are arbitrary
+    3:4-ish sizes incl. odd ones (exercises the integer-floor centre of postprocess)."""
+    rng = np.random.default_rng(seed + 1000)
+    wh = np.stack([rng.integers(31, 900, size=n), rng.integers(41, 1200, size=n)], axis=1).astype(np.int32)
+    wh[0] = (192, 256)
+    return wh

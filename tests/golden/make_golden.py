@@ -1,0 +1,164 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures by running THE REFERENCE ITSELF in this container.
+
+    python tests/golden/make_golden.py            # writes tests/golden/*.npz
+
+Runs only where ``/root/reference`` exists (the build container).  The reference
+package is imported read-only with ``sys.dont_write_bytecode`` and with empty stub
+modules for the six third-party imports that are not installed here
+(cv2, ultralytics, skimage, filterpy, torchvision, ffmpeg -- SURVEY.md 8c).  Two
+cv2 functions are on the path and get a real implementation in the stub:
+
+* ``cv2.GaussianBlur`` -> scipy.ndimage.correlate1d(mode='mirror') on both axes with
+  OpenCV's float32 ``getGaussianKernel`` weights (an implementation independent of
+  ``oracle/vitpose_cpu.gaussian_blur``; PARITY UNPINNED vs the real OpenCV binary),
+* ``cv2.resize`` -> identity, asserting the crop is already 256x192.
+
+Nothing from the reference is copied: the fixtures hold only seeds/shapes and the
+reference's numerical OUTPUTS.  While generating, the script also checks the
+``oracle/`` restatement against the reference on identical inputs and prints the
+deviations (the same checks that tests/test_oracle_golden.py repeats against the
+stored outputs).
+"""
+from __future__ import annotations
+
+import os
+import sys
+import types
+import warnings
+
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+
+import numpy as np
+import torch
+
+REF = '/root/reference'
+
+
+class _Stub(types.ModuleType):
+    def __getattr__(self, name):
+        if name.startswith('__'):
+            raise AttributeError(name)
+        return _Stub(f'{self.__name__}.{name}')
+
+    def __call__(self, *a, **k):
+        raise RuntimeError(f'stub {self.__name__} called')
+
+
+def _install_stubs():
+    from scipy.ndimage import correlate1d
+
+    for name in ['cv2', 'ultralytics', 'skimage', 'skimage.io', 'filterpy', 'filterpy.kalman',
+                 'torchvision', 'torchvision.transforms', 'torchvision.utils', 'ffmpeg',
+                 'matplotlib', 'matplotlib.pyplot', 'matplotlib.patches', 'matplotlib.cm']:
+        if name not in sys.modules:
+            try:
+                __import__(name)
+            except Exception:
+                sys.modules[name] = _Stub(name)
+    cv2 = sys.modules['cv2']
+
+    def getGaussianKernel(ksize, sigma):
+        if sigma <= 0:
+            sigma = 0.3 * ((ksize - 1) * 0.5 - 1) + 0.8
+        i = np.arange(ksize, dtype=np.float64) - (ksize - 1) * 0.5
+        w = np.exp(-(i * i) / (2 * sigma * sigma))
+        return (w / w.sum()).astype(np.float32)
+
+    def GaussianBlur(src, ksize, sigmaX, dst=None, *a, **k):
+        g = getGaussianKernel(ksize[0], sigmaX)
+        out = correlate1d(src.astype(np.float32), g, axis=1, mode='mirror')
+        out = correlate1d(out, g, axis=0, mode='mirror').astype(np.float32)
+        if dst is not None:
+            dst[...] = out
+            return dst
+        return out
+
+    def resize(img, dsize, interpolation=None):
+        assert (img.shape[1], img.shape[0]) == tuple(dsize), 'cv2.resize shim is identity only'
+        return img
+
+    cv2.GaussianBlur = GaussianBlur
+    cv2.resize = resize
+    cv2.INTER_LINEAR = 1
+
+
+def import_reference():
+    _install_stubs()
+    sys.path.insert(0, REF)
+    warnings.simplefilter('ignore')
+    import easy_ViTPose  # noqa: F401
+    from easy_ViTPose.inference import VitInference
+    from easy_ViTPose.vit_models.model import ViTPose
+    from easy_ViTPose.vit_utils.util import dyn_model_import
+    return VitInference, ViTPose, dyn_model_import
+
+
+def build_ref(VitInference, ViTPose, dyn_model_import, dataset, variant, sd_np):
+    cfg = dyn_model_import(dataset, variant)
+    model = ViTPose(cfg)
+    model.eval()
+    missing = model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd_np.items()})
+    assert not missing.missing_keys and not missing.unexpected_keys, missing
+    V = VitInference.__new__(VitInference)
+    V.device = 'cpu'
+    V.target_size = [192, 256]
+    V._vit_pose = model
+    return V
+
+
+def main():
+    from cases import org_sizes, peaked_heatmaps
+    from easy_vitpose_amd.configs import model_shape
+    from easy_vitpose_amd.synth import synthetic_crops, synthetic_state_dict
+    from oracle import vitpose_cpu as O
+
+    VitInference, ViTPose, dyn_model_import = import_reference()
+    torch.manual_seed(0)
+
+    # ---------------------------------------------------------------- decode goldens
+    for tag, (n, k, seed) in {'decode_k17': (8, 17, 11), 'decode_k133': (2, 133, 12)}.items():
+        hm = peaked_heatmaps(n, k, seed)
+        wh = org_sizes(n, seed)
+        exp = np.concatenate([VitInference.postprocess(hm[i:i + 1].copy(), int(wh[i, 0]), int(wh[i, 1]))
+                              for i in range(n)], 0).astype(np.float32)
+        mine = O.decode_per_crop(hm, wh)
+        print(f'{tag}: oracle-vs-reference max|d| = {np.abs(mine - exp).max():.3e}')
+        np.savez_compressed(os.path.join(HERE, f'{tag}.npz'), n=n, k=k, seed=seed, org_wh=wh, expected=exp)
+
+    # ----------------------------------------------------------------- model goldens
+    # (variant, dataset, n_crops, crop kind, channels kept in the fixture)
+    plan = [('s', 'coco', 2, 'noise', None), ('b', 'coco', 2, 'blobs', None),
+            ('l', 'coco_25', 1, 'blobs', None), ('h', 'wholebody', 1, 'noise', 16)]
+    for variant, dataset, n, kind, keep in plan:
+        shp = model_shape(variant, dataset)
+        sd = synthetic_state_dict(shp, seed=0)
+        V = build_ref(VitInference, ViTPose, dyn_model_import, dataset, variant, sd)
+        crops = synthetic_crops(n, seed=7, kind=kind)
+        hms, kps = [], []
+        with torch.no_grad():
+            for i in range(n):
+                x, oh, ow = V.pre_img(crops[i])
+                hms.append(V._vit_pose(torch.from_numpy(x)).numpy())
+                kps.append(V._inference_torch(crops[i]))
+        hms = np.concatenate(hms, 0)
+        kps = np.concatenate(kps, 0).astype(np.float32)
+        sdt = O.to_torch_state_dict(sd)
+        mine_hm = np.concatenate([O.model_forward(sdt, O.pre_img(crops[i])[0], shp.depth, shp.num_heads)
+                                  for i in range(n)], 0)
+        mine_kp = np.concatenate([O.inference_torch(sdt, shp.depth, shp.num_heads, crops[i]) for i in range(n)], 0)
+        print(f'model {variant}/{dataset}: heatmap max|d| = {np.abs(mine_hm - hms).max():.3e} '
+              f'(hm std {hms.std():.3f}), keypoints max|d| = {np.abs(mine_kp - kps).max():.3e}')
+        stats = np.array([hms.mean(), hms.std(), hms.min(), hms.max()], dtype=np.float64)
+        hm_store = hms if keep is None else hms[:, :keep]
+        np.savez_compressed(os.path.join(HERE, f'model_{variant}_{dataset}.npz'), variant=variant, dataset=dataset,
+                            n=n, kind=kind, crop_seed=7, weight_seed=0, heatmaps=hm_store.astype(np.float32),
+                            keypoints=kps, stats=stats)
+
+
+if __name__ == '__main__':
+    main()

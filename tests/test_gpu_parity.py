@@ -1,0 +1,189 @@
+"""GPU: the HIP path (through the C ABI) against the CPU oracle and the committed
+reference goldens, plus size-independent properties at the BASELINE batch size.
+
+Tolerances (north_star): keypoint coordinates +-0.5 px, confidences 1e-3, against the
+reference torch-CPU path.  Random-weight heatmaps are noise-like, so (SURVEY.md 7,
+"parity is ill-conditioned on random weights") coordinate parity is asserted on joints
+whose arg-max margin exceeds the heatmap error and whose DARK step is well-conditioned;
+the fraction of joints that qualifies is asserted too, and heatmap-tensor error is
+asserted on ALL joints.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from cases import org_sizes, peaked_heatmaps
+from easy_vitpose_amd import VitInference, VitPoseHip, decode_heatmaps
+from easy_vitpose_amd.synth import synthetic_crops
+from helpers import CONF_TOL, KP_TOL_PX, argmax_margin, dark_offset_px, oracle_heatmaps, weights
+from oracle import vitpose_cpu as O
+
+pytestmark = pytest.mark.gpu
+
+# measured-error budgets per operand type (heatmap std of the synthetic checkpoints ~0.3)
+HM_MAX_ERR = {'fp16': 4e-3, 'bf16': 3e-2}
+HM_RMS_ERR = {'fp16': 6e-4, 'bf16': 5e-3}
+CONF_ERR = {'fp16': CONF_TOL, 'bf16': 1.5e-2}   # bf16 operands do NOT meet the 1e-3 confidence bar
+
+
+# ----------------------------------------------------------------------------- decode
+@pytest.mark.parametrize('tag', ['decode_k17', 'decode_k133'])
+def test_decode_matches_reference_golden(golden_dir, tag):
+    z = np.load(os.path.join(golden_dir, f'{tag}.npz'))
+    n, k, seed = int(z['n']), int(z['k']), int(z['seed'])
+    hm, wh = peaked_heatmaps(n, k, seed), org_sizes(n, seed)
+    got = decode_heatmaps(hm, wh)
+    exp = z['expected']
+    assert np.array_equal(got[..., 2], exp[..., 2])              # confidences: bit exact
+    d = np.abs(got[..., :2] - exp[..., :2])
+    # flat map (crop 4, joint 5): Hessian is eps*I -> exact zero step in both
+    assert d.max() < 2e-3, f'decode vs reference golden: {d.max():.3e} px'
+    assert np.abs(got - O.decode_per_crop(hm, wh)).max() < 2e-3  # and vs the oracle
+
+
+def test_decode_large_batch_properties():
+    """BASELINE size (256 x 17 joints): batched decode == per-crop decode, permutation equivariant."""
+    hm = peaked_heatmaps(256, 17, 99)
+    full = decode_heatmaps(hm)
+    perm = np.random.default_rng(0).permutation(256)
+    assert np.array_equal(decode_heatmaps(hm[perm]), full[perm])
+    idx = [0, 1, 2, 3, 4, 100, 255]
+    single = np.concatenate([decode_heatmaps(hm[i:i + 1]) for i in idx])
+    assert np.array_equal(single, full[idx])                     # no cross-crop coupling (the reference's N*K>5084 bug)
+    ref = O.decode_per_crop(hm[:16])
+    assert np.abs(full[:16] - ref).max() < 2e-3
+
+
+# ------------------------------------------------------------------------------ model
+def _engine(variant, dataset, dtype, max_batch=8):
+    shp, sd, _ = weights(variant, dataset)
+    return VitPoseHip(shp, sd, dtype=dtype, device_id=0, max_batch=max_batch)
+
+
+@pytest.mark.parametrize('dtype', ['fp16', 'bf16'])
+@pytest.mark.parametrize('variant,dataset,n', [('s', 'coco', 6), ('b', 'coco', 6)])
+def test_model_parity_vs_oracle(variant, dataset, n, dtype):
+    crops = np.concatenate([synthetic_crops(n // 2, 7, 'blobs'), synthetic_crops(n - n // 2, 8, 'noise')])
+    ref_hm = oracle_heatmaps(variant, dataset, crops)
+    eng = _engine(variant, dataset, dtype)
+    hm = eng.heatmaps(crops)
+    err = np.abs(hm - ref_hm)
+    rms = float(np.sqrt((err ** 2).mean()))
+    print(f'[{variant}/{dtype}] heatmap std {ref_hm.std():.3f}  max|err| {err.max():.3e}  rms {rms:.3e}')
+    assert err.max() < HM_MAX_ERR[dtype] and rms < HM_RMS_ERR[dtype]
+    kp = eng.infer(crops)
+    ref_kp = O.decode_per_crop(ref_hm)
+    # decode kernel on the device heatmaps == oracle decode of the same heatmaps (isolates decode from model error)
+    assert np.array_equal(kp[..., 2], hm.reshape(n, -1, 3072).max(-1))
+    cerr = np.abs(kp[..., 2] - ref_kp[..., 2])
+    print(f'[{variant}/{dtype}] confidence max err {cerr.max():.3e} (tol {CONF_ERR[dtype]:.1e})')
+    assert cerr.max() < CONF_ERR[dtype]
+    # coordinates: joints whose arg-max cannot flip under the measured error and whose DARK step is conditioned
+    ok = (argmax_margin(ref_hm) > 4 * err.max()) & (dark_offset_px(ref_kp, ref_hm) < 1.5)
+    print(f'[{variant}/{dtype}] coordinate check on {ok.mean() * 100:.0f}% of joints')
+    assert ok.mean() > 0.15
+    d = np.abs(kp[..., :2] - ref_kp[..., :2])[ok]
+    print(f'[{variant}/{dtype}] keypoint max err {d.max():.3f} px')
+    assert d.max() < KP_TOL_PX
+    eng.close()
+
+
+@pytest.mark.parametrize('variant,dataset', [('s', 'coco'), ('b', 'coco'), ('l', 'coco_25'), ('h', 'wholebody')])
+def test_model_matches_reference_golden(golden_dir, variant, dataset):
+    """HIP heatmaps / confidences vs outputs of the reference itself (fixtures)."""
+    z = np.load(os.path.join(golden_dir, f'model_{variant}_{dataset}.npz'))
+    crops = synthetic_crops(int(z['n']), int(z['crop_seed']), str(z['kind']))
+    eng = _engine(variant, dataset, 'fp16', max_batch=2)
+    hm = eng.heatmaps(crops)
+    exp = z['heatmaps']
+    err = np.abs(hm[:, :exp.shape[1]] - exp)
+    print(f'[{variant}] vs reference golden: max|err| {err.max():.3e} (hm std {exp.std():.3f})')
+    assert err.max() < HM_MAX_ERR['fp16'] * (2 if variant in 'lh' else 1)
+    kp = eng.infer(crops)
+    assert np.abs(kp[..., 2] - z['keypoints'][..., 2]).max() < CONF_TOL * (2 if variant in 'lh' else 1)
+    eng.close()
+
+
+def test_tokens_tap_and_input_formats():
+    """Backbone output after last_norm vs oracle; uint8 NHWC input == float32 NCHW input of pre_img."""
+    shp, sd, sdt = weights('s', 'coco')
+    crops = synthetic_crops(3, 5, 'noise')
+    eng = VitPoseHip(shp, sd, dtype='fp16', max_batch=4)
+    x = np.concatenate([O.pre_img(c)[0] for c in crops])
+    import torch
+    ref_tok = O.backbone_forward(sdt, torch.from_numpy(x), shp.depth, shp.num_heads).numpy()
+    tok = eng.tokens(crops)
+    assert np.abs(tok - ref_tok).max() < 2e-2 and np.sqrt(((tok - ref_tok) ** 2).mean()) < 2e-3
+    assert np.array_equal(eng.heatmaps(crops), eng.heatmaps(x))   # device normalisation is bit-identical to pre_img
+    eng.close()
+
+
+def test_batching_edge_cases():
+    """empty batch, batch 1, ragged chunking over max_batch, determinism, batch invariance."""
+    shp, sd, _ = weights('s', 'coco')
+    eng = VitPoseHip(shp, sd, dtype='fp16', max_batch=4)
+    crops = synthetic_crops(11, 21, 'blobs')
+    assert eng.infer(crops[:0]).shape == (0, 17, 3)
+    full = eng.infer(crops)                                       # 4 + 4 + 3
+    assert np.array_equal(full, eng.infer(crops))                 # deterministic
+    assert np.array_equal(full[4:5], eng.infer(crops[4:5]))       # batch-size invariant, bit for bit
+    assert np.array_equal(full[::-1], eng.infer(crops[::-1]))     # permutation equivariant
+    wh = org_sizes(11, 5)
+    scaled = eng.infer(crops, wh)
+    assert np.array_equal(scaled[..., 2], full[..., 2])
+    exp_x = (full[..., 1].astype(np.float64) / (192 / 47.0)) * (wh[:, None, 0] / 47.0) + (wh[:, None, 0] // 2 - wh[:, None, 0] * 0.5)
+    assert np.abs(scaled[..., 1] - exp_x).max() < 1e-3 * max(1.0, float(np.abs(exp_x).max()) / 100)
+    eng.close()
+
+
+def test_state_dict_errors():
+    shp, sd, _ = weights('s', 'coco')
+    bad = dict(sd); del bad['backbone.blocks.3.mlp.fc1.weight']
+    with pytest.raises(KeyError):
+        VitPoseHip(shp, bad, max_batch=1)
+    bad = dict(sd); bad['backbone.pos_embed'] = bad['backbone.pos_embed'][:, :100]
+    with pytest.raises(RuntimeError):
+        VitPoseHip(shp, bad, max_batch=1)
+
+
+def test_baseline_batch_properties():
+    """ViTPose-B, batch 256 (BASELINE config 2): crop i of the big batch == crop i alone;
+    spot parity of 4 crops against the oracle."""
+    shp, sd, _ = weights('b', 'coco')
+    eng = VitPoseHip(shp, sd, dtype='fp16', max_batch=256)
+    crops = synthetic_crops(256, 0, 'noise')
+    crops[:8] = synthetic_crops(8, 1, 'blobs')
+    out = eng.infer(crops)
+    assert out.shape == (256, 17, 3) and np.isfinite(out).all()
+    idx = [0, 3, 100, 255]
+    assert np.array_equal(np.concatenate([eng.infer(crops[i:i + 1]) for i in idx]), out[idx])
+    ref_hm = oracle_heatmaps('b', 'coco', crops[idx])
+    ref = O.decode_per_crop(ref_hm)
+    assert np.abs(out[idx][..., 2] - ref[..., 2]).max() < CONF_TOL
+    eng.close()
+
+
+# ------------------------------------------------------------------- VitInference API
+def test_vitinference_surface_with_fake_detector():
+    shp, sd, sdt = weights('s', 'coco')
+    frame = np.zeros((480, 640, 3), np.uint8)
+    crops = synthetic_crops(2, 4, 'blobs')
+    frame[100:356, 50:242] = crops[0]
+    frame[150:406, 400:592] = crops[1]
+    boxes = np.array([[60, 110, 232, 346, 0.9], [410, 160, 582, 396, 0.8], [0, 0, 50, 50, 0.2]], dtype=np.float64)
+    model = VitInference(sd, lambda img: boxes.copy(), model_name='s', dataset='coco', max_batch=4)
+    res = model.inference(frame)
+    assert sorted(res.keys()) == [0, 1] and res[0].shape == (17, 3) and res[0].dtype == np.float32
+    # the padded boxes are exactly the 192x256 pasted crops -> per-crop oracle on the same pixels
+    for i, (x0, y0) in enumerate([(50, 100), (400, 150)]):
+        crop = frame[y0:y0 + 256, x0:x0 + 192]
+        ref = O.inference_torch(sdt, shp.depth, shp.num_heads, crop)[0]
+        ref[:, :2] += [y0, x0]
+        assert np.abs(res[i][:, 2] - ref[:, 2]).max() < CONF_TOL
+        single = model._inference(crop)
+        assert single.shape == (1, 17, 3)
+        assert np.allclose(single[0][:, :2] + [y0, x0], res[i][:, :2], atol=1e-3)
+    assert model._keypoints is res and model.frame_counter == 1
+    hm = oracle_heatmaps('s', 'coco', crops[:1])
+    assert np.abs(VitInference.postprocess(hm, 192, 256) - O.postprocess(hm.copy(), 192, 256)).max() < 2e-3
