@@ -68,3 +68,30 @@ def argmax_margin(heatmaps: np.ndarray, radius: int = 2) -> np.ndarray:
             mask = (np.abs(yy - y0) > radius) | (np.abs(xx - x0) > radius)
             out[i, j] = flat[i, j, idx[i, j]] - heatmaps[i, j][mask].max()
     return out
+
+
+def dark_conditioned(heatmaps: np.ndarray, vmin: float = 0.05) -> np.ndarray:
+    """Joints whose DARK refinement is numerically well-posed in the REFERENCE:
+    all 7 blurred samples >= vmin (the log amplifies an absolute heatmap error dv to
+    dv/v; below the 0.001 clip the map is flat), and the log-map has a proper local
+    maximum at the arg-max (negative-definite Hessian with a clear margin).  A trained
+    model's peaks satisfy this; most noise-like maps of random weights do not."""
+    n, k, H, W = heatmaps.shape
+    preds, _ = O.get_max_preds(heatmaps)
+    out = np.zeros((n, k), dtype=bool)
+    for i in range(n):
+        for j in range(k):
+            x, y = int(preds[i, j, 0]), int(preds[i, j, 1])
+            if x < 0:
+                continue
+            bp = np.pad(O.gaussian_blur(heatmaps[i, j]), 1, mode='edge')
+            px, py = x + 1, y + 1
+            s = np.array([bp[py, px], bp[py, px + 1], bp[py, px - 1], bp[py + 1, px], bp[py - 1, px],
+                          bp[py + 1, px + 1], bp[py - 1, px - 1]], dtype=np.float64)
+            if s.min() < vmin:
+                continue
+            l = np.log(s)
+            dxx, dyy = l[1] - 2 * l[0] + l[2], l[3] - 2 * l[0] + l[4]
+            dxy = 0.5 * (l[5] - l[1] - l[3] + 2 * l[0] - l[2] - l[4] + l[6])
+            out[i, j] = dxx < -0.02 and dyy < -0.02 and dxx * dyy - dxy * dxy > 0.25 * dxx * dyy
+    return out
