@@ -134,4 +134,20 @@ hipError_t layernorm_launch(int dtype, const float* x, const float* gamma, const
     return hipGetLastError();
 }
 
+
+template <class Ty>
+__global__ void fill_random16_kernel(uint16_t* p, size_t n, uint32_t seed) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        uint32_t h = (uint32_t)i * 2654435761u ^ seed;
+        h ^= h >> 16; h *= 0x7feb352du; h ^= h >> 15; h *= 0x846ca68bu; h ^= h >> 16;
+        p[i] = to_bits<Ty>((float)(h >> 8) * (2.0f / 16777216.0f) - 1.0f);
+    }
+}
+
+hipError_t fill_random16(int dtype, uint16_t* p, size_t n, uint32_t seed, hipStream_t s) {
+    if (dtype == DT_F16) hipLaunchKernelGGL(fill_random16_kernel<F16>, dim3(2048), dim3(256), 0, s, p, n, seed);
+    else hipLaunchKernelGGL(fill_random16_kernel<BF16>, dim3(2048), dim3(256), 0, s, p, n, seed);
+    return hipGetLastError();
+}
+
 }  // namespace vp

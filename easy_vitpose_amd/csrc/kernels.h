@@ -22,7 +22,7 @@ enum GemmAMode { A_DENSE = 0, A_DECONV = 1 };
 
 struct GemmArgs {
     const uint16_t* A;    // dense: [M, K] row-major.  deconv: NHWC source [B, Hin, Win, Cin]
-    const uint16_t* W;    // [Npad, K] row-major, Npad % 128 == 0 (deconv: 4 parity slabs of [Npad, K])
+    const uint16_t* W;    // [w_rows, K] row-major, zero padded rows (deconv: 4 parity slabs of [w_rows, K])
     const float* bias;    // [Npad]
     void* out;
     const float* aux;     // residual [M, ldo] / pos [192, ldo]
@@ -30,8 +30,14 @@ struct GemmArgs {
     int Hin, Win, Cin;    // deconv geometry (K = 4 * Cin)
     const uint16_t* zero; // >= 128 B of zeros (deconv border taps)
     int Kp;               // heatmap: number of keypoints (== N)
+    int w_rows;           // rows W is padded to at upload (multiple of 256); deconv parity slab = w_rows * K
+    int variant;          // tile configuration (gemm.hip Cfg0..)
+    int group_m;          // grouped tile order: m-tiles per group (<= 1: plain n-fastest order)
+    size_t w_parity_stride;  // filled by gemm_launch
 };
 hipError_t gemm_launch(int dtype, int epi, const GemmArgs& a, hipStream_t s);
+// fill a 16-bit buffer with pseudo-random values in [-1, 1) (benchmark operands)
+hipError_t fill_random16(int dtype, uint16_t* p, size_t n, uint32_t seed, hipStream_t s);
 
 // ------------------------------------------------------------------ attention
 // qkv [B*192, 3*D] 16-bit (columns = [q | k | v] x heads x head_dim, vit.py:166-167)

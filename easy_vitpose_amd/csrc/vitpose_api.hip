@@ -5,6 +5,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <unordered_map>
@@ -78,6 +79,8 @@ struct vp_ctx {
     float *hm = nullptr, *kp = nullptr, *tok = nullptr;
     // profiling
     uint32_t prof = 0;   // bit f = time kernel family f
+    int gemm_variant[VP_PROF_COUNT] = {0};   // tile configuration per GEMM family (gemm.hip)
+    int gemm_group_m[VP_PROF_COUNT] = {0};
     struct Ev { hipEvent_t a, b; int fam; double flops, bytes; };
     std::vector<Ev> evs;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
@@ -126,7 +129,7 @@ int upload_mat(vp_ctx* c, uint16_t** dst, const float* src, size_t rows, size_t 
     return VP_OK;
 }
 
-size_t pad128(size_t n) { return (n + 127) / 128 * 128; }
+size_t pad128(size_t n) { return (n + 255) / 256 * 256; }   // weight rows: multiple of the largest BN tile (256)
 
 struct Lookup {
     std::unordered_map<std::string, const vp_tensor_desc*> map;
@@ -209,6 +212,19 @@ void prof_collect(vp_ctx* c) {
     c->evs.clear();
 }
 
+// Tile configuration per GEMM family.  Defaults = best measured on MI355X (profiles/);
+// experiments override with VP_GEMM_TUNE="fam:variant:group_m,..." (fam = VP_PROF_* index).
+void apply_gemm_tuning(vp_ctx* c) {
+    if (const char* t = getenv("VP_GEMM_TUNE")) {
+        int f, v, gm, used = 0;
+        while (sscanf(t, "%d:%d:%d%n", &f, &v, &gm, &used) == 3) {
+            if (f >= 0 && f < VP_PROF_COUNT) { c->gemm_variant[f] = v; c->gemm_group_m[f] = gm; }
+            t += used;
+            if (*t == ',') ++t; else break;
+        }
+    }
+}
+
 #define LAUNCH(c, fam, flops, bytes, expr)   \
     do {                                     \
         const bool on__ = prof_begin((c), (fam), (flops), (bytes)); \
@@ -224,6 +240,9 @@ int gemm(vp_ctx* c, int fam, int epi, const uint16_t* A, const uint16_t* W, cons
     g.A = A; g.W = W; g.bias = bias; g.out = out; g.aux = aux;
     g.M = M; g.N = N; g.K = K; g.ldo = ldo;
     g.Hin = Hin; g.Win = Win; g.Cin = Cin; g.zero = c->zero; g.Kp = c->Kp;
+    g.w_rows = (int)pad128((size_t)N);
+    g.variant = c->gemm_variant[fam];
+    g.group_m = c->gemm_group_m[fam];
     const double par = (epi == vp::EPI_DECONV) ? 4.0 : 1.0;
     const double flops = 2.0 * M * (double)N * K * par;
     // algorithmic HBM bytes: each operand once, output once (+ residual read)
@@ -309,6 +328,7 @@ int vp_create(vp_handle* out, const vp_config* cfg) {
     c->D = D; c->L = cfg->depth; c->heads = h; c->Kp = cfg->num_keypoints;
     c->dtype = cfg->dtype == VP_DTYPE_F16 ? vp::DT_F16 : vp::DT_BF16;
     c->maxb = cfg->max_batch;
+    apply_gemm_tuning(c);
     auto bail = [&](int rc) { g_create_error = c->err; vp_destroy(c); return rc; };
     if ((e = hipSetDevice(cfg->device_id)) != hipSuccess) { c->err = hipGetErrorString(e); return bail(VP_ERR_HIP); }
     if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) { c->err = hipGetErrorString(e); return bail(VP_ERR_HIP); }
@@ -532,6 +552,7 @@ vp_ctx* dbg_ctx(int device, int dtype) {
     vp_ctx* c = new vp_ctx();
     c->cfg.device_id = device;
     c->dtype = dtype == VP_DTYPE_F16 ? vp::DT_F16 : vp::DT_BF16;
+    apply_gemm_tuning(c);
     return c;
 }
 int dbg_finish(vp_ctx* c, int rc) {
@@ -646,6 +667,48 @@ VP_API int vp_dbg_deconv(int32_t device, int32_t dtype, int32_t B, int32_t Hin, 
     rc = gemm(c, 0, vp::EPI_DECONV, dx, dw, db, dout, nullptr, (int)Min, 256, 4 * Cin, 256, Hin, Win, Cin);
     if (!rc && hipDeviceSynchronize() != hipSuccess) rc = fail(c, VP_ERR_HIP, "deconv kernel failed");
     if (!rc) rc = download16(c, dout, out, Min * 4 * 256);
+    return dbg_finish(c, rc);
+}
+
+
+// Time `iters` launches of one GEMM configuration on random device operands (HIP events).
+// epi as in vp_dbg_gemm (0..3); returns average milliseconds per launch in *ms_out.
+VP_API int vp_dbg_gemm_bench(int32_t device, int32_t dtype, int32_t epi, int32_t variant, int32_t group_m, int32_t M,
+                             int32_t N, int32_t K, int32_t iters, float* ms_out) {
+    if (epi < 0 || epi > 3 || M <= 0 || N <= 0 || K <= 0 || K % 64 || iters <= 0 || !ms_out)
+        return fail(nullptr, VP_ERR_INVALID, "bad gemm bench shape");
+    vp_ctx* c = dbg_ctx(device, dtype);
+    if (!c) return VP_ERR_HIP;
+    uint16_t *dA, *dW, *dO16 = nullptr;
+    float *dB, *dAux = nullptr, *dO32 = nullptr;
+    int rc;
+    const size_t MN = (size_t)M * N, wrows = pad128(N);
+    if ((rc = dalloc(c, &dA, (size_t)M * K)) || (rc = dalloc(c, &dW, wrows * K)) || (rc = dalloc(c, &dB, wrows)) ||
+        (rc = dalloc(c, &c->zero, (size_t)256)))
+        return dbg_finish(c, rc);
+    if (epi >= 2) { if ((rc = dalloc(c, &dO32, MN)) || (rc = dalloc(c, &dAux, (size_t)192 * N))) return dbg_finish(c, rc); }
+    else if ((rc = dalloc(c, &dO16, MN))) return dbg_finish(c, rc);
+    vp::fill_random16(c->dtype, dA, (size_t)M * K, 1u, nullptr);
+    vp::fill_random16(c->dtype, dW, wrows * K, 2u, nullptr);
+    hipMemset(dB, 0, wrows * 4);
+    if (dO32) hipMemset(dO32, 0, MN * 4);
+    if (dAux) hipMemset(dAux, 0, (size_t)192 * N * 4);
+    c->gemm_variant[0] = variant;
+    c->gemm_group_m[0] = group_m;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    void* outp = epi >= 2 ? (void*)dO32 : (void*)dO16;
+    const float* aux = epi == 2 ? dO32 : dAux;
+    for (int i = 0; i < 2 && !rc; ++i) rc = gemm(c, 0, epi, dA, dW, dB, outp, aux, M, N, K, N);
+    hipDeviceSynchronize();
+    hipEventRecord(e0, nullptr);
+    for (int i = 0; i < iters && !rc; ++i) rc = gemm(c, 0, epi, dA, dW, dB, outp, aux, M, N, K, N);
+    hipEventRecord(e1, nullptr);
+    if (!rc && hipDeviceSynchronize() != hipSuccess) rc = fail(c, VP_ERR_HIP, "gemm bench kernel failed");
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, e0, e1);
+    *ms_out = ms / iters;
+    hipEventDestroy(e0); hipEventDestroy(e1);
     return dbg_finish(c, rc);
 }
 

@@ -166,6 +166,9 @@ VP_API int vp_dbg_layernorm(int32_t device_id, int32_t dtype, int32_t M, int32_t
  * x [B,Hin,Win,Cin] -> NHWC [B,2Hin,2Win,256]; tensors named keypoint_head.deconv_layers.{0,1}.* */
 VP_API int vp_dbg_deconv(int32_t device_id, int32_t dtype, int32_t B, int32_t Hin, int32_t Win, int32_t Cin,
                          const float* x, const vp_tensor_desc* tensors, int32_t n_tensors, float* out);
+/* average milliseconds of `iters` launches of one GEMM tile configuration on random device operands */
+VP_API int vp_dbg_gemm_bench(int32_t device_id, int32_t dtype, int32_t epi, int32_t variant, int32_t group_m,
+                             int32_t M, int32_t N, int32_t K, int32_t iters, float* ms_out);
 
 #ifdef __cplusplus
 }
