@@ -151,3 +151,85 @@ hipError_t fill_random16(int dtype, uint16_t* p, size_t n, uint32_t seed, hipStr
 }
 
 }  // namespace vp
+
+// ---------------------------------------------------------------------------
+// Calibration micro-benchmarks (tools/ only): what this box's matrix pipe and HBM
+// deliver, measured with the same compiler and launch path as the product kernels.
+namespace vp {
+
+template <int SHAPE>
+__global__ __launch_bounds__(256, 2) void peak_mfma_kernel(float* out, int iters) {
+    u32x4 a = {0x3c003c00u + threadIdx.x, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u};
+    u32x4 b = {0x38003800u, 0x38003800u + threadIdx.x, 0x38003800u, 0x38003800u};
+    if (SHAPE == 16) {
+        f32x4 acc[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] = mfma16<F16>(a, b, acc[i]);
+        }
+        f32x4 s = acc[0];
+#pragma unroll
+        for (int i = 1; i < 16; ++i) s += acc[i];
+        if (s[0] == 12345.f) out[threadIdx.x] = s[1];
+    } else {
+        typedef __attribute__((ext_vector_type(16))) float f32x16;
+        f32x16 acc[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), acc[i], 0, 0, 0);
+        }
+        if (acc[0][0] + acc[1][1] + acc[2][2] + acc[3][3] == 12345.f) out[threadIdx.x] = acc[0][1];
+    }
+}
+
+__global__ __launch_bounds__(256) void peak_copy_kernel(const f32x4* __restrict__ in, f32x4* __restrict__ out, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) out[i] = in[i];
+}
+
+// kind 0: MFMA 16x16x32 f16, 1: MFMA 32x32x16 f16 (returns TFLOP/s); 2: float4 copy (returns TB/s read+write)
+hipError_t peak_bench(int kind, double* result) {
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    float ms = 0.f;
+    if (kind == 0 || kind == 1) {
+        float* d;
+        hipMalloc(&d, 4096);
+        const int iters = 20000, blocks = 256 * 2;
+        for (int rep = 0; rep < 2; ++rep) {
+            hipEventRecord(e0, nullptr);
+            if (kind == 0) hipLaunchKernelGGL(peak_mfma_kernel<16>, dim3(blocks), dim3(256), 0, nullptr, d, iters);
+            else hipLaunchKernelGGL(peak_mfma_kernel<32>, dim3(blocks), dim3(256), 0, nullptr, d, iters);
+            hipEventRecord(e1, nullptr);
+            hipDeviceSynchronize();
+        }
+        hipEventElapsedTime(&ms, e0, e1);
+        const double flops = (double)blocks * 4 * iters * (kind == 0 ? 16.0 * 16384 : 4.0 * 32768);
+        *result = flops / (ms * 1e-3) / 1e12;
+        hipFree(d);
+    } else {
+        const size_t n = (size_t)1 << 26;   // 64 Mi float4 = 1 GiB
+        f32x4 *a, *b;
+        hipMalloc(&a, n * 16); hipMalloc(&b, n * 16);
+        hipMemset(a, 1, n * 16);
+        for (int rep = 0; rep < 3; ++rep) {
+            hipEventRecord(e0, nullptr);
+            hipLaunchKernelGGL(peak_copy_kernel, dim3(256 * 16), dim3(256), 0, nullptr, a, b, n);
+            hipEventRecord(e1, nullptr);
+            hipDeviceSynchronize();
+        }
+        hipEventElapsedTime(&ms, e0, e1);
+        *result = 2.0 * n * 16 / (ms * 1e-3) / 1e12;
+        hipFree(a); hipFree(b);
+    }
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    return hipGetLastError();
+}
+
+}  // namespace vp

@@ -29,9 +29,11 @@
 
 namespace vp {
 
-template <int BM_, int BN_, int BK_, int WM_, int WN_, int STAGES_>
+template <int BM_, int BN_, int BK_, int WM_, int WN_, int STAGES_, int PIPE_ = 0, int DIRECT_ = 0>
 struct TileCfg {
+    static constexpr int DIRECT = DIRECT_;   // 1: fragment-shaped epilogue stores straight from registers (A/B reference)
     static constexpr int BM = BM_, BN = BN_, BK = BK_, WM = WM_, WN = WN_, STAGES = STAGES_;
+    static constexpr int PIPE = PIPE_;   // 1: issue the fragment reads of both k-halves before the first MFMA block
     static constexpr int NWM = BM / WM, NWN = BN / WN, NWAVES = NWM * NWN, NT = NWAVES * 64;
     static constexpr int ROWB = BK * 2;            // bytes per tile row
     static constexpr int SLOTS = ROWB / 16;        // 16-B slots per row (8 or 4)
@@ -50,8 +52,26 @@ template <int BK> __device__ __forceinline__ int swz(int row, int slot) {
     return BK == 64 ? (slot ^ ((row >> 1) & 7)) : (slot ^ (((row >> 3) & 1) * 3));
 }
 
-__device__ __forceinline__ float gelu_erf(float x) {   // nn.GELU(approximate='none'), vit.py:127
-    return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f));
+// nn.GELU(approximate='none') (vit.py:127) = 0.5 x (1 + erf(x / sqrt 2)).  erf by Abramowitz-Stegun 7.1.26
+// (|abs error| <= 1.5e-7, i.e. far below the rounding of the 16-bit output): one v_rcp, one v_exp, 5 fma --
+// ocml's erff costs ~3x more VALU and made the fc1 epilogue 30 % slower than the plain-bias one.
+__device__ __forceinline__ float gelu_erf(float x) {
+    const float z = fabsf(x) * 0.70710678118654752f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+    float p = fmaf(1.061405429f, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    const float e = __builtin_amdgcn_exp2f(-z * z * 1.4426950408889634f);
+    const float erf_abs = fmaf(-p * t, e, 1.0f);
+    return 0.5f * x * (1.0f + copysignf(erf_abs, x));
+}
+
+// largest number of 16-row tiles per wave (dividing TJ) whose staged C rows fit in the tile ring's LDS
+template <class C, int ES> constexpr int epi_rows_per_pass() {
+    int jp = C::TJ;
+    while (jp > 1 && C::NWM * jp * 16 * (C::BN * ES + 16) > C::LDS) jp /= 2;
+    return jp;
 }
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() {
@@ -145,6 +165,60 @@ __global__ __launch_bounds__(C::NT, 2) void gemm_kernel(GemmArgs g) {
         for (int j = 0; j < C::TJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int nk = K / C::BK;
+    if constexpr (C::PIPE == 2) {
+        // Register double-buffered fragments over a STAGES-deep LDS ring (BK = 32, one 32-deep MFMA step
+        // per barrier): while the MFMAs of tile kt run, the ds_reads of tile kt+1 (already landed and made
+        // visible by this step's barrier) fill the other fragment set and tile kt+STAGES-1 streams into the
+        // slot freed two barriers ago -- the matrix pipe never waits for LDS, only at the barrier itself.
+        static_assert(C::KK == 1 && C::STAGES >= 3, "PIPE 2 needs BK = 32 and >= 3 stages");
+        u32x4 wfA[C::TI], afA[C::TJ], wfB[C::TI], afB[C::TJ];
+        auto ldfrag = [&](u32x4(&wf)[C::TI], u32x4(&af)[C::TJ], int b) {
+            const char* sb = smem + b * C::STAGE_BYTES;
+#pragma unroll
+            for (int i = 0; i < C::TI; ++i) wf[i] = *(const u32x4*)(sb + (woff + i * 16 * C::ROWB));
+#pragma unroll
+            for (int j = 0; j < C::TJ; ++j) af[j] = *(const u32x4*)(sb + (aoff + j * 16 * C::ROWB));
+        };
+        auto settle = [&](u32x4(&wf)[C::TI], u32x4(&af)[C::TJ]) {   // make the compiler wait for a fragment set HERE
+#pragma unroll
+            for (int i = 0; i < C::TI; ++i) asm volatile("" ::"v"(wf[i]));
+#pragma unroll
+            for (int j = 0; j < C::TJ; ++j) asm volatile("" ::"v"(af[j]));
+        };
+        auto mma = [&](u32x4(&wf)[C::TI], u32x4(&af)[C::TJ]) {
+#pragma unroll
+            for (int i = 0; i < C::TI; ++i)
+#pragma unroll
+                for (int j = 0; j < C::TJ; ++j) acc[i][j] = mfma16<T>(wf[i], af[j], acc[i][j]);
+        };
+#pragma unroll
+        for (int s = 0; s < C::STAGES - 1; ++s)
+            if (s < nk) stage(s, s);
+        if (nk >= C::STAGES - 1) wait_vmcnt<C::G * (C::STAGES - 2)>();
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        ldfrag(wfA, afA, 0);
+        int nbuf = 1 % C::STAGES, pbuf = C::STAGES - 1;   // buffer of tile kt+1, buffer tile kt+STAGES-1 goes to
+        auto step = [&](int kt, u32x4(&cwf)[C::TI], u32x4(&caf)[C::TJ], u32x4(&nwf)[C::TI], u32x4(&naf)[C::TJ]) {
+            if (kt + C::STAGES - 2 < nk) wait_vmcnt<C::G * (C::STAGES - 3)>();   // tile kt+1 landed (own share)
+            else wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();   // tile kt+1 visible; every wave is done with the slot of tile kt-1
+            asm volatile("" ::: "memory");
+            settle(cwf, caf);
+            __builtin_amdgcn_sched_barrier(0);
+            if (kt + C::STAGES - 1 < nk) stage(kt + C::STAGES - 1, pbuf);
+            if (kt + 1 < nk) ldfrag(nwf, naf, nbuf);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(cwf, caf);
+            nbuf = (nbuf + 1 == C::STAGES) ? 0 : nbuf + 1;
+            pbuf = (pbuf + 1 == C::STAGES) ? 0 : pbuf + 1;
+        };
+        for (int kt = 0; kt < nk; kt += 2) {   // nk is even (K % 64 == 0, BK = 32)
+            step(kt, wfA, afA, wfB, afB);
+            step(kt + 1, wfB, afB, wfA, afA);
+        }
+    } else {
 #pragma unroll
     for (int s = 0; s < C::STAGES - 1; ++s)
         if (s < nk) stage(s, s);
@@ -155,83 +229,212 @@ __global__ __launch_bounds__(C::NT, 2) void gemm_kernel(GemmArgs g) {
         else wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();   // every wave's share of tile kt landed; everyone finished tile kt-1
         asm volatile("" ::: "memory");
-        if (kt + C::STAGES - 1 < nk) stage(kt + C::STAGES - 1, pbuf);
+        if (kt + C::STAGES - 1 < nk && !(g.ablate & 1)) stage(kt + C::STAGES - 1, pbuf);
         const char* sb = smem + buf * C::STAGE_BYTES;
+        if (C::PIPE && C::KK == 2) {
+            // software pipelined fragment reads: the ds_reads of k-half 1 are issued between the two MFMA
+            // blocks of k-half 0 and complete in their shadow (lgkmcnt is only 4 bits wide, so no more than
+            // one half's reads are outstanding at a wait); sched_barriers pin this order for the compiler.
+            u32x4 wf0[C::TI], af0[C::TJ], wf1[C::TI], af1[C::TJ];
 #pragma unroll
-        for (int kk = 0; kk < C::KK; ++kk) {
-            u32x4 wf[C::TI], af[C::TJ];
+            for (int i = 0; i < C::TI; ++i) wf0[i] = *(const u32x4*)(sb + (woff + i * 16 * C::ROWB));
 #pragma unroll
-            for (int i = 0; i < C::TI; ++i) wf[i] = *(const u32x4*)(sb + ((woff + i * 16 * C::ROWB) ^ (kk << 6)));
+            for (int j = 0; j < C::TJ; ++j) af0[j] = *(const u32x4*)(sb + (aoff + j * 16 * C::ROWB));
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-            for (int j = 0; j < C::TJ; ++j) af[j] = *(const u32x4*)(sb + ((aoff + j * 16 * C::ROWB) ^ (kk << 6)));
+            for (int i = 0; i < C::TI / 2; ++i)
+#pragma unroll
+                for (int j = 0; j < C::TJ; ++j) acc[i][j] = mfma16<T>(wf0[i], af0[j], acc[i][j]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < C::TI; ++i) wf1[i] = *(const u32x4*)(sb + ((woff + i * 16 * C::ROWB) ^ 64));
+#pragma unroll
+            for (int j = 0; j < C::TJ; ++j) af1[j] = *(const u32x4*)(sb + ((aoff + j * 16 * C::ROWB) ^ 64));
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = C::TI / 2; i < C::TI; ++i)
+#pragma unroll
+                for (int j = 0; j < C::TJ; ++j) acc[i][j] = mfma16<T>(wf0[i], af0[j], acc[i][j]);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < C::TI; ++i)
 #pragma unroll
-                for (int j = 0; j < C::TJ; ++j) acc[i][j] = mfma16<T>(wf[i], af[j], acc[i][j]);
+                for (int j = 0; j < C::TJ; ++j) acc[i][j] = mfma16<T>(wf1[i], af1[j], acc[i][j]);
+            __builtin_amdgcn_s_setprio(0);
+        } else {
+#pragma unroll
+            for (int kk = 0; kk < C::KK; ++kk) {
+                u32x4 wf[C::TI], af[C::TJ];
+#pragma unroll
+                for (int i = 0; i < C::TI; ++i) wf[i] = *(const u32x4*)(sb + ((woff + i * 16 * C::ROWB) ^ (kk << 6)));
+#pragma unroll
+                for (int j = 0; j < C::TJ; ++j) af[j] = *(const u32x4*)(sb + ((aoff + j * 16 * C::ROWB) ^ (kk << 6)));
+#pragma unroll
+                for (int i = 0; i < C::TI; ++i)
+#pragma unroll
+                    for (int j = 0; j < C::TJ; ++j) acc[i][j] = mfma16<T>(wf[i], af[j], acc[i][j]);
+            }
         }
         buf = (buf + 1 == C::STAGES) ? 0 : buf + 1;
         pbuf = (pbuf + 1 == C::STAGES) ? 0 : pbuf + 1;
     }
 
-    // ---- epilogue: lane owns 4 consecutive n (= nb..nb+3) of row m, per (i, j) ----
+    }
+
+    // ---- epilogue ----
+    // The accumulator fragment (4 consecutive n of one m per lane) would store 32-byte pieces at a row
+    // stride: measured 1.2-1.7 TB/s.  Instead the C tile goes through the (now idle) LDS ring in passes
+    // of JP row-tiles per wave and leaves as whole-row 16-byte-per-lane accesses (a wave instruction =
+    // 1 KiB of consecutive output bytes); the fp32 residual / pos operand is read the same way.
+    if constexpr (EPI != EPI_HEATMAP && !C::DIRECT) {
+        constexpr int ES = (EPI == EPI_BIAS_RESID || EPI == EPI_POS) ? 4 : 2;   // bytes per staged element
+        constexpr int ROWBYTES = C::BN * ES + 16;                               // +16 B: conflict-free fragment writes
+        constexpr int JP = epi_rows_per_pass<C, ES>();
+        constexpr int CR = C::NWM * JP * 16;                                    // rows staged per pass
+        constexpr int CPR = C::BN * ES / 16;                                    // 16-B chunks per row
+        constexpr int EPC = 16 / ES;                                            // elements per chunk
+        constexpr int NCH = CR * CPR / C::NT;                                   // chunks per thread per pass
+        static_assert(NCH * C::NT == CR * CPR, "chunks must split evenly over threads");
+        f32x4 bias4[C::TI];
 #pragma unroll
-    for (int j = 0; j < C::TJ; ++j) {
-        const int m = m0 + wm * C::WM + j * 16 + frow;
-        if (m >= g.M) continue;
-        size_t orow;
-        if (EPI == EPI_DECONV) {
-            const int t = m / g.Win, jj = m - t * g.Win, ii = t % g.Hin, img = t / g.Hin;
-            orow = ((size_t)(img * 2 * g.Hin + 2 * ii + (parity >> 1)) * (2 * g.Win) + 2 * jj + (parity & 1)) * (size_t)g.ldo;
-        } else if (EPI == EPI_HEATMAP) {
-            const int img = m / 3072, p = m - img * 3072;
-            orow = (size_t)img * g.Kp * 3072 + p;
-        } else {
-            orow = (size_t)m * g.ldo;
-        }
+        for (int i = 0; i < C::TI; ++i)
+            bias4[i] = (EPI == EPI_POS) ? f32x4{0.f, 0.f, 0.f, 0.f} : *(const f32x4*)(g.bias + n0 + wn * C::WN + i * 16 + fg * 4);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();   // every wave is done with the operand ring
 #pragma unroll
-        for (int i = 0; i < C::TI; ++i) {
-            const int nb = n0 + wn * C::WN + i * 16 + fg * 4;
-            if (nb >= g.N) continue;
-            f32x4 v = acc[i][j];
-            if (EPI != EPI_POS) {
-                const f32x4 b = *(const f32x4*)(g.bias + nb);
-                v += b;
-            }
-            if (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_DECONV) {
-                if (EPI == EPI_BIAS_GELU) {
+        for (int p = 0; p < C::TJ / JP; ++p) {
+            // this thread's output chunks of the pass: row offsets, and the fp32 residual / pos operand is
+            // fetched NOW (coalesced 16 B per lane) so its latency overlaps the LDS staging below
+            size_t orow_q[NCH];
+            f32x4 res[ES == 4 ? NCH : 1];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
-                }
+            for (int q = 0; q < NCH; ++q) {
+                const int c = tid + q * C::NT;
+                const int lr = c / CPR, ch = c - lr * CPR;
+                const int wmr = lr / (JP * 16), rr = lr - wmr * (JP * 16);
+                const int m = m0 + wmr * C::WM + p * JP * 16 + rr;
+                const int n = n0 + ch * EPC;
+                orow_q[q] = (size_t)-1;
+                if (m >= g.M || n >= g.N) continue;
                 if (EPI == EPI_DECONV) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+                    const int t = m / g.Win, jx = m - t * g.Win, ii = t % g.Hin, img = t / g.Hin;
+                    orow_q[q] = ((size_t)(img * 2 * g.Hin + 2 * ii + (parity >> 1)) * (2 * g.Win) + 2 * jx + (parity & 1)) * (size_t)g.ldo;
+                } else {
+                    orow_q[q] = (size_t)m * g.ldo;
                 }
-                u32x2 o;
-                o[0] = pack2<T>(v[0], v[1]);
-                o[1] = pack2<T>(v[2], v[3]);
-                *(u32x2*)((uint16_t*)g.out + orow + nb) = o;
-            } else if (EPI == EPI_BIAS_RESID) {
-                const f32x4 r = *(const f32x4*)(g.aux + orow + nb);
-                *(f32x4*)((float*)g.out + orow + nb) = v + r;
-            } else if (EPI == EPI_POS) {
-                const f32x4 r = *(const f32x4*)(g.aux + (size_t)(m % 192) * g.ldo + nb);
-                *(f32x4*)((float*)g.out + orow + nb) = v + r;
-            } else {  // EPI_HEATMAP: out[(img*Kp + n) * 3072 + p]
+                if (ES == 4) {
+                    const size_t arow = (EPI == EPI_POS) ? (size_t)(m % 192) * g.ldo : orow_q[q];
+                    res[q] = *(const f32x4*)(g.aux + arow + n);
+                }
+            }
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (nb + r < g.N) ((float*)g.out)[orow + (size_t)(nb + r) * 3072] = v[r];
+            for (int jj = 0; jj < JP; ++jj) {
+                char* lrow = smem + ((wm * JP + jj) * 16 + frow) * ROWBYTES + (wn * C::WN + fg * 4) * ES;
+#pragma unroll
+                for (int i = 0; i < C::TI; ++i) {
+                    f32x4 v = acc[i][p * JP + jj] + bias4[i];
+                    if (EPI == EPI_BIAS_GELU) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+                    }
+                    if (EPI == EPI_DECONV) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+                    }
+                    if (ES == 2) {
+                        u32x2 o;
+                        o[0] = pack2<T>(v[0], v[1]);
+                        o[1] = pack2<T>(v[2], v[3]);
+                        *(u32x2*)(lrow + i * 16 * ES) = o;
+                    } else {
+                        *(f32x4*)(lrow + i * 16 * ES) = v;
+                    }
+                }
+            }
+            __syncthreads();
+            if (!(g.ablate & 8)) {
+#pragma unroll
+                for (int q = 0; q < NCH; ++q) {
+                    const int c = tid + q * C::NT;
+                    const int lr = c / CPR, ch = c - lr * CPR;
+                    const int n = n0 + ch * EPC;
+                    if (orow_q[q] == (size_t)-1) continue;
+                    const char* src = smem + lr * ROWBYTES + ch * 16;
+                    if (ES == 2) {
+                        const u32x4 v = *(const u32x4*)src;
+                        uint16_t* dst = (uint16_t*)g.out + orow_q[q] + n;
+                        if (n + 8 <= g.N) *(u32x4*)dst = v;
+                        else *(u32x2*)dst = u32x2{v[0], v[1]};   // N % 8 == 4 tail (N % 4 == 0 is required)
+                    } else {
+                        *(f32x4*)((float*)g.out + orow_q[q] + n) = *(const f32x4*)src + res[q];
+                    }
+                }
+            }
+            if (p + 1 < C::TJ / JP) __syncthreads();
+        }
+    } else {
+        // direct fragment-shaped stores: EPI_HEATMAP (final 1x1 conv, few n, transposed out[(img*Kp + n)*3072 + p])
+        // and the DIRECT A/B reference configurations
+#pragma unroll
+        for (int j = 0; j < C::TJ; ++j) {
+            const int m = m0 + wm * C::WM + j * 16 + frow;
+            if (m >= g.M || (g.ablate & 8)) continue;
+            size_t orow;
+            if (EPI == EPI_DECONV) {
+                const int t = m / g.Win, jx = m - t * g.Win, ii = t % g.Hin, img = t / g.Hin;
+                orow = ((size_t)(img * 2 * g.Hin + 2 * ii + (parity >> 1)) * (2 * g.Win) + 2 * jx + (parity & 1)) * (size_t)g.ldo;
+            } else if (EPI == EPI_HEATMAP) {
+                const int img = m / 3072, pix = m - img * 3072;
+                orow = (size_t)img * g.Kp * 3072 + pix;
+            } else {
+                orow = (size_t)m * g.ldo;
+            }
+#pragma unroll
+            for (int i = 0; i < C::TI; ++i) {
+                const int nb = n0 + wn * C::WN + i * 16 + fg * 4;
+                if (nb >= g.N) continue;
+                f32x4 v = acc[i][j];
+                if (EPI != EPI_POS) v += *(const f32x4*)(g.bias + nb);
+                if (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_DECONV) {
+                    if (EPI == EPI_BIAS_GELU) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+                    }
+                    if (EPI == EPI_DECONV) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+                    }
+                    u32x2 o;
+                    o[0] = pack2<T>(v[0], v[1]);
+                    o[1] = pack2<T>(v[2], v[3]);
+                    *(u32x2*)((uint16_t*)g.out + orow + nb) = o;
+                } else if (EPI == EPI_BIAS_RESID) {
+                    *(f32x4*)((float*)g.out + orow + nb) = v + *(const f32x4*)(g.aux + orow + nb);
+                } else if (EPI == EPI_POS) {
+                    *(f32x4*)((float*)g.out + orow + nb) = v + *(const f32x4*)(g.aux + (size_t)(m % 192) * g.ldo + nb);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (nb + r < g.N) ((float*)g.out)[orow + (size_t)(nb + r) * 3072] = v[r];
+                }
             }
         }
     }
 }
 
-//                     BM   BN  BK  WM  WN  STAGES      LDS    waves
-using Cfg0 = TileCfg<128, 128, 64, 64, 64, 2>;   //  64 KiB   4   (2 blocks / CU)
-using Cfg1 = TileCfg<256, 128, 32, 128, 64, 3>;  //  72 KiB   4   (2 blocks / CU)
-using Cfg2 = TileCfg<256, 256, 64, 128, 64, 2>;  // 128 KiB   8   (1 block / CU)
-using Cfg3 = TileCfg<128, 128, 32, 64, 64, 4>;   //  64 KiB   4   (2 blocks / CU)
-using Cfg4 = TileCfg<256, 128, 64, 64, 64, 2>;   //  96 KiB   8   (1 block / CU)
-using Cfg5 = TileCfg<128, 256, 32, 64, 128, 3>;  //  72 KiB   4   (2 blocks / CU)
+// Tile configurations (id = GemmArgs::variant).  Measured on MI355X, M = 49152 (tools/gemm_tune.py,
+// profiles/gemm_tune_r1.txt): the 256x256 tile halves the L2->LDS operand traffic and wins for the
+// wide-N GEMMs (qkv, fc1); the 128x128 tile (2 blocks / CU, epilogue of one block overlaps the
+// main loop of the other) wins for N = D.
+//                    BM   BN  BK   WM  WN  STAGES PIPE DIRECT      LDS   waves
+using Cfg0 = TileCfg<128, 128, 64, 64, 64, 2, 0, 0>;    //  64 KiB   4   (2 blocks / CU)
+using Cfg1 = TileCfg<128, 128, 64, 64, 64, 2, 1, 0>;    //  same + pipelined fragment reads
+using Cfg2 = TileCfg<256, 256, 64, 128, 64, 2, 0, 0>;   // 128 KiB   8   (1 block / CU)
+using Cfg3 = TileCfg<256, 256, 64, 128, 64, 2, 1, 0>;   //  same + pipelined fragment reads
+using Cfg4 = TileCfg<256, 256, 32, 128, 64, 4, 2, 0>;   // 128 KiB   8   4-stage ring, register double-buffered fragments
+using Cfg5 = TileCfg<128, 128, 64, 64, 64, 2, 0, 1>;    //  Cfg0 with fragment-shaped epilogue stores (A/B reference)
+static constexpr int NUM_TILE_CFGS = 6;
 
 template <class T, int EPI, int AMODE, class C>
 static hipError_t launch(const GemmArgs& a, hipStream_t s) {

@@ -34,10 +34,14 @@ struct GemmArgs {
     int variant;          // tile configuration (gemm.hip Cfg0..)
     int group_m;          // grouped tile order: m-tiles per group (<= 1: plain n-fastest order)
     size_t w_parity_stride;  // filled by gemm_launch
+    int ablate;           // profiling only (tools/gemm_ablate.py): 1 = no operand loads after the prologue, 8 = no epilogue stores
 };
 hipError_t gemm_launch(int dtype, int epi, const GemmArgs& a, hipStream_t s);
 // fill a 16-bit buffer with pseudo-random values in [-1, 1) (benchmark operands)
 hipError_t fill_random16(int dtype, uint16_t* p, size_t n, uint32_t seed, hipStream_t s);
+
+// calibration micro-benchmarks (tools/): kind 0/1 = MFMA 16x16x32 / 32x32x16 f16 TFLOP/s, 2 = float4 copy TB/s
+hipError_t peak_bench(int kind, double* result);
 
 // ------------------------------------------------------------------ attention
 // qkv [B*192, 3*D] 16-bit (columns = [q | k | v] x heads x head_dim, vit.py:166-167)

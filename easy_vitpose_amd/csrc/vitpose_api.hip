@@ -79,8 +79,9 @@ struct vp_ctx {
     float *hm = nullptr, *kp = nullptr, *tok = nullptr;
     // profiling
     uint32_t prof = 0;   // bit f = time kernel family f
-    int gemm_variant[VP_PROF_COUNT] = {0};   // tile configuration per GEMM family (gemm.hip)
+    int gemm_variant[VP_PROF_COUNT] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1};   // tile cfg per GEMM family, -1 = default rule
     int gemm_group_m[VP_PROF_COUNT] = {0};
+    int gemm_ablate = 0;   // profiling only
     struct Ev { hipEvent_t a, b; int fam; double flops, bytes; };
     std::vector<Ev> evs;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
@@ -243,6 +244,16 @@ int gemm(vp_ctx* c, int fam, int epi, const uint16_t* A, const uint16_t* W, cons
     g.w_rows = (int)pad128((size_t)N);
     g.variant = c->gemm_variant[fam];
     g.group_m = c->gemm_group_m[fam];
+    if (g.variant < 0) {   // default choice, measured on MI355X (profiles/gemm_tune_r1.txt)
+        g.variant = 0; g.group_m = 0;
+        if (epi == vp::EPI_BIAS || epi == vp::EPI_BIAS_GELU) {          // wide N (qkv, fc1): 256x256 tile
+            if (M >= 2048 && N >= 1024) { g.variant = 3; g.group_m = 8; }
+            else { g.variant = 1; g.group_m = 8; }
+        } else if (epi == vp::EPI_BIAS_RESID && K >= 2 * N) {            // fc2: long K, N = D
+            g.variant = 1; g.group_m = 8;
+        }
+    }
+    g.ablate = c->gemm_ablate;
     const double par = (epi == vp::EPI_DECONV) ? 4.0 : 1.0;
     const double flops = 2.0 * M * (double)N * K * par;
     // algorithmic HBM bytes: each operand once, output once (+ residual read)
@@ -693,8 +704,9 @@ VP_API int vp_dbg_gemm_bench(int32_t device, int32_t dtype, int32_t epi, int32_t
     hipMemset(dB, 0, wrows * 4);
     if (dO32) hipMemset(dO32, 0, MN * 4);
     if (dAux) hipMemset(dAux, 0, (size_t)192 * N * 4);
-    c->gemm_variant[0] = variant;
+    c->gemm_variant[0] = variant & 0xff;
     c->gemm_group_m[0] = group_m;
+    c->gemm_ablate = variant >> 8;   // tools only: ablation flags in the high bits
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
     void* outp = epi >= 2 ? (void*)dO32 : (void*)dO16;
@@ -710,6 +722,15 @@ VP_API int vp_dbg_gemm_bench(int32_t device, int32_t dtype, int32_t epi, int32_t
     *ms_out = ms / iters;
     hipEventDestroy(e0); hipEventDestroy(e1);
     return dbg_finish(c, rc);
+}
+
+
+// Calibration: kind 0/1 = MFMA-only loop (16x16x32 / 32x32x16 f16) in TFLOP/s, 2 = float4 copy in TB/s (read+write).
+VP_API int vp_dbg_peak(int32_t device, int32_t kind, double* result) {
+    if (!result || kind < 0 || kind > 2) return fail(nullptr, VP_ERR_INVALID, "bad argument");
+    if (hipSetDevice(device) != hipSuccess) return fail(nullptr, VP_ERR_HIP, "no HIP device");
+    hipError_t e = vp::peak_bench(kind, result);
+    return e == hipSuccess ? VP_OK : fail(nullptr, VP_ERR_HIP, hipGetErrorString(e));
 }
 
 }  // extern "C"

@@ -169,6 +169,8 @@ VP_API int vp_dbg_deconv(int32_t device_id, int32_t dtype, int32_t B, int32_t Hi
 /* average milliseconds of `iters` launches of one GEMM tile configuration on random device operands */
 VP_API int vp_dbg_gemm_bench(int32_t device_id, int32_t dtype, int32_t epi, int32_t variant, int32_t group_m,
                              int32_t M, int32_t N, int32_t K, int32_t iters, float* ms_out);
+/* calibration of the box: kind 0/1 = MFMA-only loop 16x16x32 / 32x32x16 f16 (TFLOP/s), 2 = float4 copy (TB/s) */
+VP_API int vp_dbg_peak(int32_t device_id, int32_t kind, double* result);
 
 #ifdef __cplusplus
 }

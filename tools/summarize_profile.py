@@ -1,41 +1,43 @@
 #!/usr/bin/env python3
-"""Condense rocprofv3 output dirs (tools/profile.sh) into a small text summary for profiles/."""
-import csv
+"""Condense the rocprofv3 (rocpd sqlite) outputs of tools/profile.sh into a small text
+summary that is committed under profiles/.
+
+    python tools/summarize_profile.py gpurun_out/prof_<tag> > profiles/<name>.txt
+"""
 import glob
 import os
+import re
+import sqlite3
 import sys
-from collections import defaultdict
 
 root = sys.argv[1]
 
 
 def short(name):
-    name = name.replace('void vp::', '').replace('vp::', '')
-    return name[:110]
+    name = re.sub(r'\(.*$', '', name.replace('void ', '').replace('vp::', ''))
+    return name[:100]
 
 
-def find(pattern):
-    return sorted(glob.glob(os.path.join(root, pattern), recursive=True))
+def dbs(sub):
+    return sorted(glob.glob(os.path.join(root, sub, '**', '*.db'), recursive=True))
 
 
-for f in find('stats/**/*kernel_stats.csv'):
-    print(f'== kernel stats ({os.path.relpath(f, root)})')
-    rows = list(csv.DictReader(open(f)))
-    for r in rows[:25]:
-        print(f"{short(r['Name']):110s} calls {r['Calls']:>6s} total_ns {r['TotalDurationNs']:>12s} avg_ns {float(r['AverageNs']):12.1f} pct {r['Percentage']}")
-for d in ('pmc_sq', 'pmc_tcc', 'pmc_fetch', 'pmc_write'):
-    for f in find(f'{d}/**/*counter_collection.csv'):
-        acc = defaultdict(lambda: defaultdict(float))
-        cnt = defaultdict(int)
-        seen = set()
-        for r in csv.DictReader(open(f)):
-            k = short(r['Kernel_Name'])
-            acc[k][r['Counter_Name']] += float(r['Counter_Value'])
-            key = (k, r['Dispatch_Id'])
-            if key not in seen:
-                seen.add(key)
-                cnt[k] += 1
-        print(f'== {d}: per-kernel counter sums / dispatch counts')
-        for k in sorted(acc, key=lambda k: -sum(acc[k].values()))[:14]:
-            vals = '  '.join(f'{c}={v / cnt[k]:.4g}' for c, v in sorted(acc[k].items()))
-            print(f'{k:110s} n={cnt[k]:4d}  per-dispatch: {vals}')
+for db in dbs('stats'):
+    cur = sqlite3.connect(db).cursor()
+    print(f'== rocprofv3 --kernel-trace --stats : {os.path.relpath(db, root)}  (durations in us)')
+    print(f"{'kernel':100s} {'calls':>6s} {'total_us':>12s} {'avg_us':>10s} {'pct':>6s}")
+    for name, calls, total, avg, pct in cur.execute('select name,total_calls,total_duration,average,percentage from top_kernels limit 16'):
+        print(f'{short(name):100s} {calls:6d} {total:12.1f} {avg:10.2f} {pct:6.2f}')
+for sub in ('pmc_sq', 'pmc_tcc', 'pmc_fetch', 'pmc_write'):
+    for db in dbs(sub):
+        cur = sqlite3.connect(db).cursor()
+        rows = cur.execute('''select kernel_name, counter_name, sum(value), count(distinct dispatch_id), avg(duration)
+                              from counters_collection group by kernel_name, counter_name''').fetchall()
+        per = {}
+        for k, c, v, n, dur in rows:
+            per.setdefault(k, {'n': n, 'dur': dur})[c] = v / n
+        print(f'== rocprofv3 --pmc ({sub}): per-dispatch averages (sum over SEs/XCDs / dispatches)')
+        for k in sorted(per, key=lambda k: -per[k]['dur'] * per[k]['n'])[:12]:
+            d = per[k]
+            vals = '  '.join(f'{c}={v:.5g}' for c, v in sorted(d.items()) if c not in ('n', 'dur'))
+            print(f"{short(k):100s} n={d['n']:4d} avg_ns={d['dur']:.0f}  {vals}")
