@@ -34,7 +34,7 @@ PEAK_MFMA_16BIT = 2.5e15   # dense bf16/fp16 MFMA peak, MI355X_MICROARCH.md (256
 PEAK_HBM = 8.0e12
 
 
-def cpu_baseline(variant, dataset, budget_s=20.0):
+def cpu_baseline(variant, dataset, budget_s=15.0):
     """Reference-equivalent CPU path (oracle/ restatement of _inference_torch, per crop,
     batch 1 exactly like VitInference) on a bounded sample of the same synthetic crops.
 
@@ -51,7 +51,7 @@ def cpu_baseline(variant, dataset, budget_s=20.0):
         avail = os.cpu_count() or 1
     shp = model_shape(variant, dataset)
     sd = O.to_torch_state_dict(synthetic_state_dict(shp, 0))
-    crops = synthetic_crops(64, 0, 'noise')
+    crops = synthetic_crops(256, 0, 'noise')
     run = lambda i: O.inference_torch(sd, shp.depth, shp.num_heads, crops[i])
     best_t, best_dt = None, None
     for t in sorted({min(avail, c) for c in (8, 16, 32, 64)}):

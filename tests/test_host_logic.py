@@ -1,0 +1,131 @@
+"""CPU: host-side logic and the C-ABI surface (no compute calls without a GPU)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from easy_vitpose_amd import _capi as capi
+from easy_vitpose_amd import configs
+from easy_vitpose_amd.inference import pad_image, resize_bilinear_u8
+from easy_vitpose_amd.parallel import shard_bounds
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_shape_table_matches_reference_configs():
+    # ViTPose_common.py:65-195 and the per-dataset out_channels
+    assert configs.VARIANTS == {'s': (384, 12, 12), 'b': (768, 12, 12), 'l': (1024, 24, 16), 'h': (1280, 32, 16)}
+    assert configs.DATASET_KEYPOINTS['coco'] == 17 and configs.DATASET_KEYPOINTS['coco_25'] == 25
+    assert configs.DATASET_KEYPOINTS['wholebody'] == 133 and configs.DATASET_KEYPOINTS['ap10k'] == 17
+    s = configs.model_shape('h', 'wholebody')
+    assert (s.head_dim, s.mlp_dim, s.num_keypoints) == (80, 5120, 133)
+    # algorithmic GFLOP per person, SURVEY.md 8(d) / BASELINE.md
+    for (v, d), gf in {('s', 'coco'): 11.188, ('b', 'coco'): 37.046, ('l', 'coco_25'): 123.151, ('h', 'wholebody'): 251.842}.items():
+        assert abs(configs.model_shape(v, d).gflop_per_person() - gf) < 2e-3
+    with pytest.raises(AssertionError):
+        configs.model_shape('x', 'coco')
+    with pytest.raises(AssertionError):
+        configs.model_shape('b', 'imagenet')
+
+
+def test_infer_dataset_by_path_like_reference():
+    assert configs.infer_dataset_by_path('/a/b/vitpose-b-coco_25.pth') == 'coco_25'
+    assert configs.infer_dataset_by_path('vitpose-h-wholebody.pth') == 'wholebody'
+    with pytest.raises(ValueError):
+        configs.infer_dataset_by_path('model.pth')
+
+
+def test_pad_image_contract():
+    img = np.arange(10 * 30 * 3, dtype=np.uint8).reshape(10, 30, 3)      # wide -> pad rows
+    out, (left, top) = pad_image(img, 3 / 4)
+    assert out.shape == (40, 30, 3) and (left, top) == (0, 15)
+    assert np.array_equal(out[15:25], img) and out[:15].sum() == 0 and out[25:].sum() == 0
+    img = np.ones((40, 10, 3), np.uint8)                                 # tall -> pad columns
+    out, (left, top) = pad_image(img, 3 / 4)
+    assert out.shape == (40, 30, 3) and (left, top) == (10, 0) and out[:, 10:20].min() == 1
+    img = np.ones((256, 192, 3), np.uint8)
+    out, pads = pad_image(img, 3 / 4)
+    assert out.shape == (256, 192, 3) and pads == (0, 0)
+
+
+def test_resize_identity_and_bilinear():
+    img = np.random.default_rng(0).integers(0, 256, (256, 192, 3), dtype=np.uint8)
+    assert resize_bilinear_u8(img, (192, 256)) is img
+    # exact 2x down-scale with half-pixel centres = mean of 2x2 blocks (rounded half up)
+    big = np.random.default_rng(1).integers(0, 256, (512, 384, 3), dtype=np.uint8)
+    ref = np.floor(big.reshape(256, 2, 192, 2, 3).astype(np.float64).mean(axis=(1, 3)) + 0.5).astype(np.uint8)
+    assert np.array_equal(resize_bilinear_u8(big, (192, 256)), ref)
+    const = np.full((100, 75, 3), 77, np.uint8)
+    assert (resize_bilinear_u8(const, (192, 256)) == 77).all()
+
+
+def test_shard_bounds_cover_and_balance():
+    for n in (0, 1, 7, 8, 64, 65, 257):
+        for w in (1, 2, 4, 8):
+            spans = [shard_bounds(n, w, r) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            per = -(-n // w) if n else 0
+            assert all(hi - lo <= per for lo, hi in spans)
+
+
+def test_library_loads_and_exports_every_header_symbol():
+    hdr = open(os.path.join(ROOT, 'include', 'vitpose_hip.h')).read()
+    declared = sorted(set(re.findall(r'VP_API\s+[\w\s\*]+?\b(vp_\w+)\s*\(', hdr)))
+    assert len(declared) >= 15
+    lib = capi.load_library()
+    for name in declared:
+        assert hasattr(lib, name), f'{name} declared in the header but not exported'
+    assert sorted(capi.SYMBOLS) == declared, 'ctypes binding list and header disagree'
+    assert lib.vp_abi_version() == 1
+    # struct layout the header promises
+    assert C.sizeof(capi.vp_config) == 28 and C.sizeof(capi.vp_tensor_desc) == 24
+    assert C.sizeof(capi.vp_profile) == capi.VP_PROF_COUNT * 8 * 4
+
+
+def test_bad_config_is_rejected_before_touching_a_device():
+    lib = capi.load_library()
+    h = C.c_void_p()
+    for cfg in [capi.vp_config(770, 12, 12, 17, 0, 0, 4), capi.vp_config(768, 12, 7, 17, 0, 0, 4),
+                capi.vp_config(768, 12, 12, 0, 0, 0, 4), capi.vp_config(768, 12, 12, 17, 9, 0, 4)]:
+        assert lib.vp_create(C.byref(h), C.byref(cfg)) == capi.VP_ERR_INVALID
+        assert capi.last_error()
+    assert lib.vp_create(None, None) == capi.VP_ERR_INVALID
+
+
+def test_no_cpu_fallback_fails_loudly():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip('GPU present')
+    lib = capi.load_library()
+    h = C.c_void_p()
+    cfg = capi.vp_config(384, 12, 12, 17, 0, 0, 2)
+    assert lib.vp_create(C.byref(h), C.byref(cfg)) == capi.VP_ERR_HIP
+    assert 'no CPU fallback' in capi.last_error()
+    out = np.zeros((1, 17, 3), np.float32)
+    hm = np.zeros((1, 17, 64, 48), np.float32)
+    assert lib.vp_decode_only(0, hm.ctypes.data, 1, 17, None, out.ctypes.data) == capi.VP_ERR_HIP
+    from easy_vitpose_amd import VitPoseHip
+    from easy_vitpose_amd.synth import synthetic_state_dict
+    shp = configs.model_shape('s', 'coco')
+    with pytest.raises(capi.VpError):
+        VitPoseHip(shp, {}, max_batch=1)
+
+
+def test_missing_extension_raises(monkeypatch):
+    monkeypatch.setattr(capi, '_lib', None)
+    monkeypatch.setattr(capi, 'LIB_PATH', '/nonexistent/libvitpose_hip.so')
+    with pytest.raises(capi.HipExtensionMissing):
+        capi.load_library()
+
+
+def test_product_never_imports_the_oracle():
+    """oracle/ is test infrastructure: nothing under easy_vitpose_amd/ may reference it."""
+    pkg = os.path.join(ROOT, 'easy_vitpose_amd')
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(('.py', '.hip', '.h')):
+                src = open(os.path.join(dirpath, f), errors='ignore').read()
+                assert not re.search(r'^\s*(from|import)\s+oracle\b', src, re.M), f'{f} imports the oracle'
