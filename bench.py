@@ -73,6 +73,22 @@ def cpu_baseline(variant, dataset, budget_s=15.0):
                       f'{dt:.1f} s, torch {torch.__version__} with {best_t} threads (best of 8/16/32/64; host has {avail} hw threads)'}
 
 
+def pmc_traffic(args):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of THIS command
+    (profiles/pmc_r1.json, made by tools/profile.sh + tools/summarize_profile.py; FETCH_SIZE x2 on gfx950 as
+    MI355X_MICROARCH.md prescribes).  None when the configuration differs from the profiled one."""
+    path = os.path.join(ROOT, 'profiles', 'pmc_r1.json')
+    if not (os.path.exists(path) and args.variant == 'b' and args.batch == 256 and args.dtype == 'fp16' and args.gpus == 1):
+        return None
+    try:
+        for k, d in json.load(open(path)).items():
+            if k.startswith('gemm_kernel<F16, 1, 0') and 'hbm_bytes_per_dispatch' in d:
+                return d['hbm_bytes_per_dispatch']
+    except Exception:
+        pass
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -131,7 +147,7 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    dom = 'gemm_proj_fc2'
+    dom = 'gemm_fc1'   # dominant kernel symbol by time (rocprofv3 stats, profiles/): the fc1 GEMM, bias+GELU epilogue
     eng.set_profiling([dom])
     eng.reset_profile()
     fence()
@@ -175,9 +191,9 @@ def main():
                        'gflop_per_person': round(shp.gflop_per_person(), 3)},
             'model_tflops': round(persons_s * shp.gflop_per_person() / 1e3, 1),
             'model_frac_of_mfma_peak': round(persons_s * shp.gflop_per_person() * 1e9 / PEAK_MFMA_16BIT, 4),
-            'roofline': {'bound': 'mfma', 'kernel': 'gemm_kernel<EPI_BIAS_RESID> (attn.proj + mlp.fc2, fp32 residual epilogue)',
+            'roofline': {'bound': 'mfma', 'kernel': 'gemm_kernel<EPI_BIAS_GELU, 256x256x64 tile> (mlp.fc1 + bias + GELU, M=B*192, N=4D, K=D)',
                          'achieved': round(ach / 1e12, 2), 'peak': PEAK_MFMA_16BIT / 1e12, 'unit': 'TFLOP/s',
-                         'frac': round(ach / PEAK_MFMA_16BIT, 4), 'traffic': None,
+                         'frac': round(ach / PEAK_MFMA_16BIT, 4), 'traffic': pmc_traffic(args),
                          'launches': d['launches'], 'avg_launch_ms': round(d['ms'] / max(d['launches'], 1), 5),
                          'flops_per_launch_avg': d['flops'] / max(d['launches'], 1)},
         }

@@ -11,6 +11,8 @@ import sqlite3
 import sys
 
 root = sys.argv[1]
+json_out = sys.argv[2] if len(sys.argv) > 2 else None
+pmc_json = {}
 
 
 def short(name):
@@ -39,5 +41,16 @@ for sub in ('pmc_sq', 'pmc_tcc', 'pmc_fetch', 'pmc_write'):
         print(f'== rocprofv3 --pmc ({sub}): per-dispatch averages (sum over SEs/XCDs / dispatches)')
         for k in sorted(per, key=lambda k: -per[k]['dur'] * per[k]['n'])[:12]:
             d = per[k]
+            pmc_json.setdefault(short(k), {}).update({c: v for c, v in d.items() if c not in ('n', 'dur')})
+            pmc_json[short(k)].setdefault('avg_ns_' + sub, d['dur'])
             vals = '  '.join(f'{c}={v:.5g}' for c, v in sorted(d.items()) if c not in ('n', 'dur'))
             print(f"{short(k):100s} n={d['n']:4d} avg_ns={d['dur']:.0f}  {vals}")
+
+if json_out:
+    import json
+    # HBM traffic per dispatch, MI355X_MICROARCH.md "HBM": FETCH_SIZE / WRITE_SIZE are KiB from separate --pmc
+    # passes; on gfx950 FETCH_SIZE counts 64 B per 128-B request -> x2 (calibrated here on layernorm: 151 MB read).
+    for k, d in pmc_json.items():
+        if 'FETCH_SIZE' in d and 'WRITE_SIZE' in d:
+            d['hbm_bytes_per_dispatch'] = (2.0 * d['FETCH_SIZE'] + d['WRITE_SIZE']) * 1024.0
+    json.dump(pmc_json, open(json_out, 'w'), indent=1, sort_keys=True)
