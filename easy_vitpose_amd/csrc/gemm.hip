@@ -218,6 +218,69 @@ __global__ __launch_bounds__(C::NT, 2) void gemm_kernel(GemmArgs g) {
             step(kt, wfA, afA, wfB, afB);
             step(kt + 1, wfB, afB, wfA, afA);
         }
+    } else if constexpr (C::PIPE == 3) {
+        // Staggered two-group schedule (8 waves, BK = 32, 4-stage LDS ring).  Waves 0-3 (group A) and 4-7
+        // (group B) run the same LOAD -> barrier -> MFMA -> barrier sequence one barrier apart, so in every
+        // barrier interval one wave of each SIMD streams its 32 MFMAs while its SIMD partner reads the next
+        // fragments from LDS and issues the global_load_lds of tile k+3: the matrix pipe and the LDS/TA
+        // pipes are busy simultaneously instead of alternately.
+        //   A: LOAD(k) between barriers 2k..2k+1, MFMA(k) between 2k+1..2k+2;  B: one barrier later.
+        //   tile j: issued in LOAD(j-3) into slot j%4 (last read in LOAD(j-4), >= 1 barrier earlier),
+        //   landed before barrier 2j because every LOAD phase ends with vmcnt(2G) (two younger tiles in flight).
+        static_assert(C::KK == 1 && C::STAGES == 4 && C::NWAVES == 8, "PIPE 3: BK = 32, 4 stages, 8 waves");
+        const bool grp_b = __builtin_amdgcn_readfirstlane(tid) >= 256;
+        u32x4 wf[C::TI], af[C::TJ];
+#pragma unroll
+        for (int s = 0; s < 3; ++s)
+            if (s < nk) stage(s, s);
+        if (nk >= 3) wait_vmcnt<2 * C::G>();
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (grp_b) {
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        }
+        int rbuf = 0, pbuf = 3;
+        for (int k = 0; k < nk; ++k) {
+            // ---- LOAD(k)
+            const char* sb = smem + rbuf * C::STAGE_BYTES;
+#pragma unroll
+            for (int i = 0; i < C::TI; ++i) wf[i] = *(const u32x4*)(sb + (woff + i * 16 * C::ROWB));
+#pragma unroll
+            for (int j = 0; j < C::TJ; ++j) af[j] = *(const u32x4*)(sb + (aoff + j * 16 * C::ROWB));
+            if (k + 3 < nk) {
+                if (!(g.ablate & 1)) stage(k + 3, pbuf);
+                wait_vmcnt<2 * C::G>();
+            } else if (k + 2 < nk) {
+                wait_vmcnt<C::G>();
+            } else {
+                wait_vmcnt<0>();
+            }
+#pragma unroll
+            for (int i = 0; i < C::TI; ++i) asm volatile("" ::"v"(wf[i]));   // fragments complete before the barrier
+#pragma unroll
+            for (int j = 0; j < C::TJ; ++j) asm volatile("" ::"v"(af[j]));
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            // ---- MFMA(k)
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int i = 0; i < C::TI; ++i)
+#pragma unroll
+                for (int j = 0; j < C::TJ; ++j) acc[i][j] = mfma16<T>(wf[i], af[j], acc[i][j]);
+            __builtin_amdgcn_s_setprio(0);
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            rbuf = (rbuf + 1) & 3;
+            pbuf = (pbuf + 1) & 3;
+        }
+        if (!grp_b) {
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        }
     } else {
 #pragma unroll
     for (int s = 0; s < C::STAGES - 1; ++s)
@@ -423,10 +486,12 @@ __global__ __launch_bounds__(C::NT, 2) void gemm_kernel(GemmArgs g) {
     }
 }
 
-// Tile configurations (id = GemmArgs::variant).  Measured on MI355X, M = 49152 (tools/gemm_tune.py,
-// profiles/gemm_tune_r1.txt): the 256x256 tile halves the L2->LDS operand traffic and wins for the
-// wide-N GEMMs (qkv, fc1); the 128x128 tile (2 blocks / CU, epilogue of one block overlaps the
-// main loop of the other) wins for N = D.
+// Tile configurations (id = GemmArgs::variant).  Measured on MI355X at M = 49152 (tools/gemm_tune.py,
+// profiles/gemm_tune_r1.txt).  Default = Cfg8: one 192-token crop per m-tile, so the tile count divides
+// evenly over 256 CUs x 2 resident blocks for every encoder GEMM (no tail wave), and the epilogue of one
+// block overlaps the main loop of its CU partner.  The others are kept as measured alternatives:
+// 256x256 halves the L2->LDS operand traffic but runs 1 block / CU (epilogue exposed, tail wave at N = D);
+// Cfg6 is the staggered two-group (anti-phase wave pairs) schedule; Cfg5 the fragment-store A/B reference.
 //                    BM   BN  BK   WM  WN  STAGES PIPE DIRECT      LDS   waves
 using Cfg0 = TileCfg<128, 128, 64, 64, 64, 2, 0, 0>;    //  64 KiB   4   (2 blocks / CU)
 using Cfg1 = TileCfg<128, 128, 64, 64, 64, 2, 1, 0>;    //  same + pipelined fragment reads
@@ -434,7 +499,10 @@ using Cfg2 = TileCfg<256, 256, 64, 128, 64, 2, 0, 0>;   // 128 KiB   8   (1 bloc
 using Cfg3 = TileCfg<256, 256, 64, 128, 64, 2, 1, 0>;   //  same + pipelined fragment reads
 using Cfg4 = TileCfg<256, 256, 32, 128, 64, 4, 2, 0>;   // 128 KiB   8   4-stage ring, register double-buffered fragments
 using Cfg5 = TileCfg<128, 128, 64, 64, 64, 2, 0, 1>;    //  Cfg0 with fragment-shaped epilogue stores (A/B reference)
-static constexpr int NUM_TILE_CFGS = 6;
+using Cfg6 = TileCfg<256, 256, 32, 128, 64, 4, 3, 0>;   // 128 KiB   8   staggered two-group schedule
+using Cfg7 = TileCfg<192, 256, 64, 96, 64, 2, 1, 0>;    // 112 KiB   8   (1 block / CU)
+using Cfg8 = TileCfg<192, 128, 64, 96, 64, 2, 1, 0>;    //  80 KiB   4   (2 blocks / CU)  <- default
+static constexpr int NUM_TILE_CFGS = 9;
 
 template <class T, int EPI, int AMODE, class C>
 static hipError_t launch(const GemmArgs& a, hipStream_t s) {
@@ -464,6 +532,9 @@ static hipError_t by_variant(const GemmArgs& a, hipStream_t s) {
         case 3: return launch<T, EPI, AMODE, Cfg3>(a, s);
         case 4: return launch<T, EPI, AMODE, Cfg4>(a, s);
         case 5: return launch<T, EPI, AMODE, Cfg5>(a, s);
+        case 6: return launch<T, EPI, AMODE, Cfg6>(a, s);
+        case 7: return launch<T, EPI, AMODE, Cfg7>(a, s);
+        case 8: return launch<T, EPI, AMODE, Cfg8>(a, s);
     }
     return hipErrorInvalidValue;
 }

@@ -244,16 +244,13 @@ int gemm(vp_ctx* c, int fam, int epi, const uint16_t* A, const uint16_t* W, cons
     g.w_rows = (int)pad128((size_t)N);
     g.variant = c->gemm_variant[fam];
     g.group_m = c->gemm_group_m[fam];
-    if (g.variant < 0) {   // default choice, measured on MI355X (profiles/gemm_tune_r1.txt)
-        g.variant = 0; g.group_m = 0;
-        if (epi == vp::EPI_BIAS || epi == vp::EPI_BIAS_GELU) {          // wide N (qkv, fc1): 256x256 tile
-            if (M >= 2048 && N >= 1024) { g.variant = 3; g.group_m = 8; }
-            else { g.variant = 1; g.group_m = 8; }
-        } else if (epi == vp::EPI_BIAS_RESID && K >= 2 * N) {            // fc2: long K, N = D
-            g.variant = 1; g.group_m = 8;
-        }
+    if (g.variant < 0) {
+        // default: the 192(m) x 128(n) tile -- M is always a multiple of 192 tokens (one crop per m-tile), so
+        // the tile count divides evenly over 256 CUs x 2 blocks at the BASELINE batch; best or tied for every
+        // encoder GEMM in the MI355X sweep (profiles/gemm_tune_r1.txt).  Wide-N GEMMs use the grouped order.
+        g.variant = 8;
+        g.group_m = (epi == vp::EPI_BIAS || epi == vp::EPI_BIAS_GELU) ? 8 : 0;
     }
-    g.ablate = c->gemm_ablate;
     const double par = (epi == vp::EPI_DECONV) ? 4.0 : 1.0;
     const double flops = 2.0 * M * (double)N * K * par;
     // algorithmic HBM bytes: each operand once, output once (+ residual read)
