@@ -115,7 +115,7 @@ __global__ __launch_bounds__(C::NT, 2) void gemm_kernel(GemmArgs g) {
 #pragma unroll
     for (int p = 0; p < C::AP; ++p) {
         const int r = (p * C::NWAVES + wave) * C::RPG + rip;
-        int m = m0 + r;
+        int m = ((g.ablate & 2) ? 0 : m0) + r;   // ablate 2 (tools): every tile loads the A rows of m-tile 0
         if (m > g.M - 1) m = g.M - 1;
         const int sl = swz<C::BK>(r, pslot) * 8;
         if (AMODE == A_DENSE) {

@@ -34,7 +34,7 @@ struct GemmArgs {
     int variant;          // tile configuration (gemm.hip Cfg0..)
     int group_m;          // grouped tile order: m-tiles per group (<= 1: plain n-fastest order)
     size_t w_parity_stride;  // filled by gemm_launch
-    int ablate;           // profiling only (tools/gemm_ablate.py): 1 = no operand loads after the prologue, 8 = no epilogue stores
+    int ablate;           // profiling only (tools/gemm_ablate.py): 1 = no operand loads after the prologue, 2 = every tile loads the A rows of m-tile 0 (A L2-resident), 8 = no epilogue stores
 };
 hipError_t gemm_launch(int dtype, int epi, const GemmArgs& a, hipStream_t s);
 // fill a 16-bit buffer with pseudo-random values in [-1, 1) (benchmark operands)

@@ -244,6 +244,7 @@ int gemm(vp_ctx* c, int fam, int epi, const uint16_t* A, const uint16_t* W, cons
     g.w_rows = (int)pad128((size_t)N);
     g.variant = c->gemm_variant[fam];
     g.group_m = c->gemm_group_m[fam];
+    g.ablate = c->gemm_ablate;
     if (g.variant < 0) {
         // default: the 192(m) x 128(n) tile -- M is always a multiple of 192 tokens (one crop per m-tile), so
         // the tile count divides evenly over 256 CUs x 2 blocks at the BASELINE batch; best or tied for every
