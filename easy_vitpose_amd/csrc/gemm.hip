@@ -502,7 +502,8 @@ using Cfg5 = TileCfg<128, 128, 64, 64, 64, 2, 0, 1>;    //  Cfg0 with fragment-s
 using Cfg6 = TileCfg<256, 256, 32, 128, 64, 4, 3, 0>;   // 128 KiB   8   staggered two-group schedule
 using Cfg7 = TileCfg<192, 256, 64, 96, 64, 2, 1, 0>;    // 112 KiB   8   (1 block / CU)
 using Cfg8 = TileCfg<192, 128, 64, 96, 64, 2, 1, 0>;    //  80 KiB   4   (2 blocks / CU)  <- default
-static constexpr int NUM_TILE_CFGS = 9;
+using Cfg9 = TileCfg<64, 64, 64, 32, 32, 2, 0, 0>;      //  32 KiB   4   (5 blocks / CU)  small batches: enough tiles to fill 256 CUs
+static constexpr int NUM_TILE_CFGS = 10;
 
 template <class T, int EPI, int AMODE, class C>
 static hipError_t launch(const GemmArgs& a, hipStream_t s) {
@@ -535,6 +536,7 @@ static hipError_t by_variant(const GemmArgs& a, hipStream_t s) {
         case 6: return launch<T, EPI, AMODE, Cfg6>(a, s);
         case 7: return launch<T, EPI, AMODE, Cfg7>(a, s);
         case 8: return launch<T, EPI, AMODE, Cfg8>(a, s);
+        case 9: return launch<T, EPI, AMODE, Cfg9>(a, s);
     }
     return hipErrorInvalidValue;
 }

@@ -251,6 +251,12 @@ int gemm(vp_ctx* c, int fam, int epi, const uint16_t* A, const uint16_t* W, cons
         // encoder GEMM in the MI355X sweep (profiles/gemm_tune_r1.txt).  Wide-N GEMMs use the grouped order.
         g.variant = 8;
         g.group_m = (epi == vp::EPI_BIAS || epi == vp::EPI_BIAS_GELU) ? 8 : 0;
+        // small batches (e.g. 8 crops per GPU of a sharded frame): fall back to tiles that still give the
+        // 256 CUs at least one block each
+        const long par_ = (epi == vp::EPI_DECONV) ? 4 : 1;
+        const long t192 = (long)((M + 191) / 192) * ((N + 127) / 128) * par_;
+        const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128) * par_;
+        if (t192 < 384) { g.variant = (t128 >= 256) ? 1 : 9; g.group_m = 0; }
     }
     const double par = (epi == vp::EPI_DECONV) ? 4.0 : 1.0;
     const double flops = 2.0 * M * (double)N * K * par;
