@@ -233,3 +233,63 @@ hipError_t peak_bench(int kind, double* result) {
 }
 
 }  // namespace vp
+
+// ---------------------------------------------------------------------------
+// Crop preparation on device: for every detected box, crop the frame, zero-pad to 3:4
+// (pad_image, vit_utils/inference.py:41-70) and resize to 256x192 exactly as OpenCV's 8-bit INTER_LINEAR
+// does (easy_ViTPose/inference.py:316): half-pixel centres, 11-bit fixed-point coefficients, int32
+// horizontal pass, (((b0*(S0>>4))>>16)+((b1*(S1>>4))>>16)+2)>>2 vertical pass, 2x2 box average at exactly
+// 2x.  Integer arithmetic -> bit-identical to easy_vitpose_amd/cropprep.py.  One block = one output row.
+namespace vp {
+
+struct AxisCoef { int s0, s1, a0, a1; };
+
+__device__ __forceinline__ AxisCoef axis_coef(int d, int dsize, int ssize) {
+    const double inv = (double)dsize / (double)ssize;
+    const double scale = 1.0 / inv;
+    float f = (float)__dsub_rn(__dmul_rn((double)d + 0.5, scale), 0.5);
+    int s = (int)floorf(f);
+    f = __fsub_rn(f, (float)s);
+    if (s < 0) { f = 0.f; s = 0; }
+    if (s >= ssize - 1) { f = 0.f; s = ssize - 1; }
+    AxisCoef c;
+    c.s0 = s;
+    c.s1 = min(s + 1, ssize - 1);
+    c.a1 = (int)rintf(__fmul_rn(f, 2048.f));
+    c.a0 = (int)rintf(__fmul_rn(__fsub_rn(1.f, f), 2048.f));
+    return c;
+}
+
+__global__ __launch_bounds__(192) void crop_resize_kernel(const uint8_t* __restrict__ frame, int FH, int FW,
+                                                          const int32_t* __restrict__ params, uint8_t* __restrict__ out) {
+    const int crop = blockIdx.x >> 8, oy = blockIdx.x & 255, ox = threadIdx.x;
+    const int32_t* p = params + crop * 8;
+    const int x0 = p[0], y0 = p[1], cw = p[2], ch = p[3], left = p[4], top = p[5], pw = p[6], ph = p[7];
+    auto px = [&](int Y, int X, int c) -> int {   // padded-canvas pixel
+        const int yy = Y - top, xx = X - left;
+        if ((unsigned)yy >= (unsigned)ch || (unsigned)xx >= (unsigned)cw) return 0;
+        return frame[((size_t)(y0 + yy) * FW + (x0 + xx)) * 3 + c];
+    };
+    uint8_t* dst = out + (((size_t)crop * 256 + oy) * 192 + ox) * 3;
+    if (pw == 384 && ph == 512) {                 // exactly 2x: OpenCV's INTER_LINEAR == fast INTER_AREA
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+            dst[c] = (uint8_t)((px(2 * oy, 2 * ox, c) + px(2 * oy, 2 * ox + 1, c) + px(2 * oy + 1, 2 * ox, c) +
+                                px(2 * oy + 1, 2 * ox + 1, c) + 2) >> 2);
+        return;
+    }
+    const AxisCoef cx = axis_coef(ox, 192, pw), cy = axis_coef(oy, 256, ph);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const int r0 = px(cy.s0, cx.s0, c) * cx.a0 + px(cy.s0, cx.s1, c) * cx.a1;
+        const int r1 = px(cy.s1, cx.s0, c) * cx.a0 + px(cy.s1, cx.s1, c) * cx.a1;
+        dst[c] = (uint8_t)((((cy.a0 * (r0 >> 4)) >> 16) + ((cy.a1 * (r1 >> 4)) >> 16) + 2) >> 2);
+    }
+}
+
+hipError_t crop_resize_launch(const uint8_t* frame, int FH, int FW, const int32_t* params, uint8_t* out, int n, hipStream_t s) {
+    hipLaunchKernelGGL(crop_resize_kernel, dim3(n * 256), dim3(192), 0, s, frame, FH, FW, params, out);
+    return hipGetLastError();
+}
+
+}  // namespace vp

@@ -55,6 +55,9 @@ hipError_t layernorm_launch(int dtype, const float* x, const float* gamma, const
 // crops -> im2col patch matrix [B*192, 768] 16-bit (k = c*256 + ky*16 + kx, zero border of 2 px)
 hipError_t im2col_launch(int dtype, const void* crops, int input_format, uint16_t* out, int B, hipStream_t s);
 
+// frame u8 [FH,FW,3] + params int32 [n,8] (x0,y0,cw,ch,left,top,pw,ph) -> crops u8 [n,256,192,3]
+hipError_t crop_resize_launch(const uint8_t* frame, int FH, int FW, const int32_t* params, uint8_t* out, int n, hipStream_t s);
+
 // --------------------------------------------------------------------- decode
 // heatmaps fp32 [N, K, 64, 48] -> out fp32 [N, K, 3] (y, x, conf); org_wh int32 [N,2] or null
 hipError_t decode_launch(const float* hm, const int32_t* org_wh, float* out, int N, int K, hipStream_t s);

@@ -77,6 +77,9 @@ struct vp_ctx {
     float* x = nullptr;
     uint16_t *y = nullptr, *qkv = nullptr, *hid = nullptr, *d1 = nullptr, *d2 = nullptr;
     float *hm = nullptr, *kp = nullptr, *tok = nullptr;
+    uint8_t* frame_stage = nullptr;   // device copy of the current video frame (vp_infer_frame)
+    size_t frame_cap = 0;
+    int32_t* cparams = nullptr;       // per-crop geometry [max_batch, 8]
     // profiling
     uint32_t prof = 0;   // bit f = time kernel family f
     int gemm_variant[VP_PROF_COUNT] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1};   // tile cfg per GEMM family, -1 = default rule
@@ -479,6 +482,44 @@ int vp_infer_tokens(vp_handle c, const void* crops, int32_t fmt, int32_t n, floa
     return VP_OK;
 }
 
+int vp_infer_frame(vp_handle c, const uint8_t* frame, int32_t fh, int32_t fw, const int32_t* crop_params, int32_t n, float* out) {
+    int rc = check_ready(c, VP_INPUT_U8_NHWC, n, frame, out);
+    if (rc) return rc;
+    if (fh <= 0 || fw <= 0 || (n > 0 && !crop_params)) return fail(c, VP_ERR_INVALID, "bad frame geometry");
+    const size_t fbytes = (size_t)fh * fw * 3;
+    if (fbytes > c->frame_cap) {
+        void* q = nullptr;
+        HIPCHK(c, hipMalloc(&q, fbytes + 256));
+        c->allocs.push_back(q);      // the old (smaller) staging buffer is released with the handle
+        c->frame_stage = (uint8_t*)q;
+        c->frame_cap = fbytes;
+    }
+    if (!c->cparams && (rc = dalloc(c, &c->cparams, (size_t)c->maxb * 8))) return rc;
+    for (int i = 0; i < n; ++i) {
+        const int32_t* p = crop_params + 8 * (size_t)i;
+        if (p[0] < 0 || p[1] < 0 || p[2] <= 0 || p[3] <= 0 || p[0] + p[2] > fw || p[1] + p[3] > fh || p[4] < 0 || p[5] < 0 ||
+            p[4] + p[2] > p[6] || p[5] + p[3] > p[7])
+            return fail(c, VP_ERR_INVALID, "crop " + std::to_string(i) + " lies outside the frame / its padded canvas");
+    }
+    HIPCHK(c, hipMemcpyAsync(c->frame_stage, frame, fbytes, hipMemcpyHostToDevice, c->stream));
+    for (int off = 0; off < n; off += c->maxb) {
+        const int nb = (n - off < c->maxb) ? n - off : c->maxb;
+        HIPCHK(c, hipMemcpyAsync(c->cparams, crop_params + 8 * (size_t)off, (size_t)nb * 32, hipMemcpyHostToDevice, c->stream));
+        LAUNCH(c, VP_PROF_IM2COL, 0.0, (double)nb * 256 * 192 * 3 * 5,
+               vp::crop_resize_launch(c->frame_stage, fh, fw, c->cparams, (uint8_t*)c->in_stage, nb, c->stream));
+        // decode scales by the padded-canvas size (pw, ph) of each crop = the image pre_img receives
+        std::vector<int32_t> wh((size_t)nb * 2);
+        for (int i = 0; i < nb; ++i) { wh[2 * i] = crop_params[8 * (size_t)(off + i) + 6]; wh[2 * i + 1] = crop_params[8 * (size_t)(off + i) + 7]; }
+        HIPCHK(c, hipMemcpyAsync(c->wh_stage, wh.data(), (size_t)nb * 8, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));   // wh is a stack-lifetime host buffer
+        if ((rc = forward_chunk(c, c->in_stage, VP_INPUT_U8_NHWC, nb, false))) return rc;
+        if ((rc = decode_chunk(c, c->wh_stage, c->kp, nb))) return rc;
+        HIPCHK(c, hipMemcpyAsync(out + (size_t)off * c->Kp * 3, c->kp, (size_t)nb * c->Kp * 12, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    return VP_OK;
+}
+
 int vp_decode_only(int32_t device_id, const float* heatmaps, int32_t n, int32_t k, const int32_t* org_wh, float* out) {
     if (!heatmaps || !out || n <= 0 || k <= 0) return fail(nullptr, VP_ERR_INVALID, "bad argument");
     int ndev = 0;
@@ -728,6 +769,25 @@ VP_API int vp_dbg_gemm_bench(int32_t device, int32_t dtype, int32_t epi, int32_t
     return dbg_finish(c, rc);
 }
 
+
+// frame + crop geometry -> the uint8 [n,256,192,3] crops the model is fed (device crop/pad/resize kernel alone)
+VP_API int vp_dbg_crop_prep(int32_t device, const uint8_t* frame, int32_t fh, int32_t fw, const int32_t* crop_params, int32_t n, uint8_t* out) {
+    if (!frame || !crop_params || !out || n <= 0 || fh <= 0 || fw <= 0) return fail(nullptr, VP_ERR_INVALID, "bad argument");
+    vp_ctx* c = dbg_ctx(device, VP_DTYPE_F16);
+    if (!c) return VP_ERR_HIP;
+    uint8_t *df, *dout;
+    int32_t* dp;
+    int rc;
+    const size_t fb = (size_t)fh * fw * 3, ob = (size_t)n * 256 * 192 * 3;
+    if ((rc = dalloc(c, &df, fb)) || (rc = dalloc(c, &dout, ob)) || (rc = dalloc(c, &dp, (size_t)n * 8))) return dbg_finish(c, rc);
+    hipError_t e = hipMemcpy(df, frame, fb, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(dp, crop_params, (size_t)n * 32, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = vp::crop_resize_launch(df, fh, fw, dp, dout, n, nullptr);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipMemcpy(out, dout, ob, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) rc = fail(c, VP_ERR_HIP, std::string("crop_prep: ") + hipGetErrorString(e));
+    return dbg_finish(c, rc);
+}
 
 // Calibration: kind 0/1 = MFMA-only loop (16x16x32 / 32x32x16 f16) in TFLOP/s, 2 = float4 copy in TB/s (read+write).
 VP_API int vp_dbg_peak(int32_t device, int32_t kind, double* result) {

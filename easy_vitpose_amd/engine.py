@@ -96,6 +96,19 @@ class VitPoseHip:
         capi.check(self.lib.vp_infer_device(self._h, d_crops.data_ptr(), fmt, n, whp, d_out.data_ptr(), int(sync)), self._h)
         return d_out
 
+    def infer_frame(self, frame: np.ndarray, params: np.ndarray) -> np.ndarray:
+        """Whole frame + crop geometry (cropprep.crop_params) -> [n, K, 3] in padded-crop pixels (vp_infer_frame)."""
+        frame = np.ascontiguousarray(frame)
+        assert frame.dtype == np.uint8 and frame.ndim == 3 and frame.shape[2] == 3
+        params = np.ascontiguousarray(params, dtype=np.int32).reshape(-1, 8)
+        n = params.shape[0]
+        out = np.empty((n, self.K, 3), dtype=np.float32)
+        if n == 0:
+            return out
+        capi.check(self.lib.vp_infer_frame(self._h, frame.ctypes.data, frame.shape[0], frame.shape[1],
+                                           params.ctypes.data, n, out.ctypes.data), self._h)
+        return out
+
     def heatmaps(self, crops: np.ndarray) -> np.ndarray:
         crops = np.ascontiguousarray(crops)
         n = crops.shape[0]
@@ -156,4 +169,15 @@ def decode_heatmaps(heatmaps: np.ndarray, org_wh=None, device_id: int = 0) -> np
     out = np.empty((n, k, 3), dtype=np.float32)
     wh = None if org_wh is None else np.ascontiguousarray(org_wh, dtype=np.int32).reshape(n, 2)
     capi.check(lib.vp_decode_only(device_id, hm.ctypes.data, n, k, None if wh is None else wh.ctypes.data, out.ctypes.data))
+    return out
+
+
+def crop_prep_device(frame: np.ndarray, params: np.ndarray, device_id: int = 0) -> np.ndarray:
+    """The device crop/pad/resize kernel alone (vp_dbg_crop_prep): uint8 [n, 256, 192, 3]."""
+    lib = capi.load_library()
+    frame = np.ascontiguousarray(frame, dtype=np.uint8)
+    params = np.ascontiguousarray(params, dtype=np.int32).reshape(-1, 8)
+    out = np.empty((len(params), IMG_H, IMG_W, 3), dtype=np.uint8)
+    capi.check(lib.vp_dbg_crop_prep(device_id, frame.ctypes.data, frame.shape[0], frame.shape[1], params.ctypes.data,
+                                    len(params), out.ctypes.data))
     return out

@@ -22,6 +22,7 @@ from typing import Optional
 import numpy as np
 
 from .configs import IMG_H, IMG_W, infer_dataset_by_path, infer_variant_from_state_dict, model_shape
+from .cropprep import crop_params, resize_linear_u8
 from .engine import VitPoseHip, decode_heatmaps
 
 __all__ = ['VitInference']
@@ -52,27 +53,6 @@ def pad_image(image: np.ndarray, aspect_ratio: float):
         out = np.zeros((th, w) + image.shape[2:], dtype=image.dtype)
         out[top:top + h] = image
     return out, (left, top)
-
-
-def resize_bilinear_u8(img: np.ndarray, size_wh) -> np.ndarray:
-    """Host bilinear resize (half-pixel centres, edge clamp) standing in for
-    ``cv2.resize(..., INTER_LINEAR)`` (inference.py:316).  Identity at equal size.
-    NOTE: OpenCV uses 11-bit fixed-point coefficients on uint8; results can differ by
-    one grey level -- parity with OpenCV is unpinned (no OpenCV in this image)."""
-    tw, th = size_wh
-    h, w = img.shape[:2]
-    if (w, h) == (tw, th):
-        return img
-    ys = (np.arange(th) + 0.5) * (h / th) - 0.5
-    xs = (np.arange(tw) + 0.5) * (w / tw) - 0.5
-    y0 = np.floor(ys).astype(int); x0 = np.floor(xs).astype(int)
-    fy = (ys - y0)[:, None, None]; fx = (xs - x0)[None, :, None]
-    y0c, y1c = np.clip(y0, 0, h - 1), np.clip(y0 + 1, 0, h - 1)
-    x0c, x1c = np.clip(x0, 0, w - 1), np.clip(x0 + 1, 0, w - 1)
-    f = img.astype(np.float64)
-    top = f[y0c][:, x0c] * (1 - fx) + f[y0c][:, x1c] * fx
-    bot = f[y1c][:, x0c] * (1 - fx) + f[y1c][:, x1c] * fx
-    return np.clip(np.floor(top * (1 - fy) + bot * fy + 0.5), 0, 255).astype(np.uint8)
 
 
 class VitInference:
@@ -180,17 +160,19 @@ class VitInference:
     def pre_img(self, img):
         """inference.py:314-318 -- kept for API compatibility (host float path)."""
         org_h, org_w = img.shape[:2]
-        img_input = resize_bilinear_u8(img, self.target_size) / 255
+        img_input = resize_linear_u8(img, self.target_size) / 255
         img_input = ((img_input - MEAN) / STD).transpose(2, 0, 1)[None].astype(np.float32)
         return img_input, org_h, org_w
 
     def _inference_batch(self, crops: "list[np.ndarray]") -> np.ndarray:
-        """N crops (uint8 RGB, any size, already padded to 3:4) -> ``[N, K, 3]``: resize on the host
-        (identity for 256x192), then ONE call into the HIP library (normalisation is on device)."""
+        """N crops (uint8 RGB, any size, already padded to 3:4) -> ``[N, K, 3]``: OpenCV-style 8-bit bilinear
+        resize on the host (cropprep.resize_linear_u8; identity for 256x192), then ONE call into the HIP
+        library (normalisation is on device).  `inference(img)` does not use this: it hands the whole frame
+        to the device crop kernel (`vp_infer_frame`)."""
         if len(crops) == 0:
             return np.empty((0, self._vit_pose.K, 3), dtype=np.float32)
         wh = np.array([[c.shape[1], c.shape[0]] for c in crops], dtype=np.int32)
-        batch = np.stack([resize_bilinear_u8(np.ascontiguousarray(c), self.target_size) for c in crops])
+        batch = np.stack([resize_linear_u8(np.ascontiguousarray(c), self.target_size) for c in crops])
         return self._vit_pose.infer(batch, wh)
 
     def _inference_hip(self, img: np.ndarray) -> np.ndarray:
@@ -216,14 +198,12 @@ class VitInference:
         if ids is None:
             ids = range(len(bboxes))
 
-        crops, offsets = [], []
-        for bbox in bboxes:
-            bbox[[0, 2]] = np.clip(bbox[[0, 2]] + [-pad_bbox, pad_bbox], 0, img.shape[1])
-            bbox[[1, 3]] = np.clip(bbox[[1, 3]] + [-pad_bbox, pad_bbox], 0, img.shape[0])
-            img_inf, (left_pad, top_pad) = pad_image(img[bbox[1]:bbox[3], bbox[0]:bbox[2]], 3 / 4)
-            crops.append(img_inf)
-            offsets.append(bbox[:2][::-1] - [top_pad, left_pad])
-        kps = self._inference_batch(crops)
+        # crop + zero-pad to 3:4 + resize + normalise all happen on device from ONE copy of the frame
+        params = crop_params(bboxes, img.shape[:2], pad_bbox) if len(bboxes) else np.zeros((0, 8), np.int32)
+        for i in range(len(bboxes)):                       # keep the reference's in-place box update (:261-262)
+            bboxes[i] = (params[i, 0], params[i, 1], params[i, 0] + params[i, 2], params[i, 1] + params[i, 3])
+        offsets = [np.array([p[1] - p[5], p[0] - p[4]]) for p in params]   # bbox[:2][::-1] - [top_pad, left_pad]
+        kps = self._vit_pose.infer_frame(np.ascontiguousarray(img), params)
 
         frame_keypoints, scores_bbox = {}, {}
         for i, (id_, score) in enumerate(zip(ids, scores)):

@@ -122,6 +122,14 @@ VP_API int vp_infer(vp_handle h, const void* crops, int32_t input_format, int32_
 VP_API int vp_infer_device(vp_handle h, const void* d_crops, int32_t input_format, int32_t n,
                     const int32_t* d_org_wh, float* d_out, int32_t sync);
 
+/* Whole-frame entry: the crop loop of VitInference.inference (inference.py:259-266) on device.
+ * frame = uint8 RGB [fh, fw, 3] on the host; crop_params = n x 8 int32 {x0, y0, cw, ch, left_pad, top_pad, pw, ph}:
+ * the +10 px padded & clipped box (:261-262) and the zero-pad geometry of pad_image (vit_utils/inference.py:41-70).
+ * One H2D of the frame; crop + zero-pad + OpenCV-style 8-bit bilinear resize (:316) + normalisation run on device.
+ * out = float32 [n, K, 3] (y, x, conf) in padded-crop pixels; the caller adds (y0 - top_pad, x0 - left_pad) as :270 does. */
+VP_API int vp_infer_frame(vp_handle h, const uint8_t* frame, int32_t fh, int32_t fw, const int32_t* crop_params,
+                          int32_t n, float* out);
+
 /* Parity/debug taps.  Heatmaps = ViTPose.forward output, float32 [N, K, 64, 48]. */
 VP_API int vp_infer_heatmaps(vp_handle h, const void* crops, int32_t input_format, int32_t n, float* heatmaps);
 /* Backbone output after last_norm (vit.py:387), float32 [N, 192, D]. */
@@ -166,6 +174,9 @@ VP_API int vp_dbg_layernorm(int32_t device_id, int32_t dtype, int32_t M, int32_t
  * x [B,Hin,Win,Cin] -> NHWC [B,2Hin,2Win,256]; tensors named keypoint_head.deconv_layers.{0,1}.* */
 VP_API int vp_dbg_deconv(int32_t device_id, int32_t dtype, int32_t B, int32_t Hin, int32_t Win, int32_t Cin,
                          const float* x, const vp_tensor_desc* tensors, int32_t n_tensors, float* out);
+/* the device crop / zero-pad / resize kernel alone: uint8 crops [n, 256, 192, 3] */
+VP_API int vp_dbg_crop_prep(int32_t device_id, const uint8_t* frame, int32_t fh, int32_t fw, const int32_t* crop_params,
+                            int32_t n, uint8_t* out);
 /* average milliseconds of `iters` launches of one GEMM tile configuration on random device operands */
 VP_API int vp_dbg_gemm_bench(int32_t device_id, int32_t dtype, int32_t epi, int32_t variant, int32_t group_m,
                              int32_t M, int32_t N, int32_t K, int32_t iters, float* ms_out);

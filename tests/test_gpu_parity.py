@@ -200,3 +200,26 @@ def test_vitinference_surface_with_fake_detector():
     assert model._keypoints is res and model.frame_counter == 1
     hm = peaked_heatmaps(1, 17, 5)
     assert np.abs(VitInference.postprocess(hm, 192, 256) - O.postprocess(hm.copy(), 192, 256)).max() < 2e-3
+
+
+def test_device_crop_prep_bit_exact_and_frame_entry():
+    """SURVEY.md 8f-1: crop + zero-pad + OpenCV-style resize on device == the host restatement, bit for bit;
+    vp_infer_frame == vp_infer on the host-prepared crops."""
+    from easy_vitpose_amd.cropprep import crop_params, prepare_crops_host
+    from easy_vitpose_amd.engine import crop_prep_device
+    rng = np.random.default_rng(17)
+    frame = rng.integers(0, 256, (720, 1280, 3), dtype=np.uint8)
+    boxes = np.array([[60, 110, 232, 346], [0, 0, 50, 300], [1200, 600, 1280, 720], [300, 100, 700, 650],
+                      [500, 200, 874, 702], [10, 10, 1270, 700], [640, 300, 660, 340]], dtype=np.float64)
+    boxes = np.concatenate([boxes, np.ones((len(boxes), 1))], 1)
+    p = crop_params(boxes, frame.shape[:2])
+    p[4] = (500, 200, 384, 512, 0, 0, 384, 512)           # exactly 2x -> box-average path
+    host = prepare_crops_host(frame, p)
+    dev = crop_prep_device(frame, p)
+    assert np.array_equal(dev, host), f'{(dev != host).sum()} differing bytes'
+    shp, sd, _ = weights('s', 'coco')
+    eng = VitPoseHip(shp, sd, dtype='fp16', max_batch=4)   # 7 crops -> chunks of 4 + 3
+    a = eng.infer_frame(frame, p)
+    b = eng.infer(host, p[:, 6:8])
+    assert np.array_equal(a, b)
+    eng.close()

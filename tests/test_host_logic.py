@@ -8,7 +8,8 @@ import pytest
 
 from easy_vitpose_amd import _capi as capi
 from easy_vitpose_amd import configs
-from easy_vitpose_amd.inference import pad_image, resize_bilinear_u8
+from easy_vitpose_amd.cropprep import crop_params, prepare_crops_host, resize_linear_u8
+from easy_vitpose_amd.inference import pad_image
 from easy_vitpose_amd.parallel import shard_bounds
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -50,15 +51,41 @@ def test_pad_image_contract():
     assert out.shape == (256, 192, 3) and pads == (0, 0)
 
 
-def test_resize_identity_and_bilinear():
+def test_resize_restates_opencv_fixed_point_bilinear():
     img = np.random.default_rng(0).integers(0, 256, (256, 192, 3), dtype=np.uint8)
-    assert resize_bilinear_u8(img, (192, 256)) is img
-    # exact 2x down-scale with half-pixel centres = mean of 2x2 blocks (rounded half up)
+    assert resize_linear_u8(img, (192, 256)) is img
+    # exactly 2x: OpenCV switches INTER_LINEAR to the 2x2 box average, (sum + 2) >> 2
     big = np.random.default_rng(1).integers(0, 256, (512, 384, 3), dtype=np.uint8)
-    ref = np.floor(big.reshape(256, 2, 192, 2, 3).astype(np.float64).mean(axis=(1, 3)) + 0.5).astype(np.uint8)
-    assert np.array_equal(resize_bilinear_u8(big, (192, 256)), ref)
-    const = np.full((100, 75, 3), 77, np.uint8)
-    assert (resize_bilinear_u8(const, (192, 256)) == 77).all()
+    ref = ((big.astype(np.int64).reshape(256, 2, 192, 2, 3).sum(axis=(1, 3)) + 2) >> 2).astype(np.uint8)
+    assert np.array_equal(resize_linear_u8(big, (192, 256)), ref)
+    assert (resize_linear_u8(np.full((100, 75, 3), 77, np.uint8), (192, 256)) == 77).all()
+    # generic scale: within one grey level of exact (float64) half-pixel-centre bilinear interpolation
+    src = np.random.default_rng(2).integers(0, 256, (300, 225, 3), dtype=np.uint8)
+    ys = (np.arange(256) + 0.5) * (300 / 256) - 0.5; xs = (np.arange(192) + 0.5) * (225 / 192) - 0.5
+    y0 = np.clip(np.floor(ys).astype(int), 0, 299); x0 = np.clip(np.floor(xs).astype(int), 0, 224)
+    y1 = np.clip(y0 + 1, 0, 299); x1 = np.clip(x0 + 1, 0, 224)
+    fy = np.clip(ys - np.floor(ys), 0, 1)[:, None, None] * (ys >= 0)[:, None, None]
+    fx = np.clip(xs - np.floor(xs), 0, 1)[None, :, None] * (xs >= 0)[None, :, None]
+    f = src.astype(np.float64)
+    exact = (f[y0][:, x0] * (1 - fx) + f[y0][:, x1] * fx) * (1 - fy) + (f[y1][:, x0] * (1 - fx) + f[y1][:, x1] * fx) * fy
+    assert np.abs(resize_linear_u8(src, (192, 256)).astype(np.float64) - exact).max() <= 1.0
+
+
+def test_crop_params_follow_reference_geometry():
+    frame = np.random.default_rng(3).integers(0, 256, (480, 640, 3), dtype=np.uint8)
+    boxes = np.array([[60, 110, 232, 346, 0.9], [0, 0, 50, 300, 0.5], [600, 400, 640, 480, 0.7]])
+    p = crop_params(boxes, frame.shape[:2])
+    assert p[0].tolist() == [50, 100, 192, 256, 0, 0, 192, 256]          # +10 px, already 3:4
+    assert p[1].tolist() == [0, 0, 60, 310, 86, 0, 232, 310]            # clipped at 0, tall -> padded left/right
+    assert p[2].tolist() == [590, 390, 50, 90, 8, 0, 67, 90]            # clipped at the frame border
+    crops = prepare_crops_host(frame, p)
+    assert crops.shape == (3, 256, 192, 3)
+    assert np.array_equal(crops[0], frame[100:356, 50:242])             # identity resize of the exact box
+    # same as the reference's two steps: pad_image then resize
+    for i, (x0, y0, cw, ch, left, top, pw, ph) in enumerate(p):
+        padded, (l, t) = pad_image(frame[y0:y0 + ch, x0:x0 + cw], 3 / 4)
+        assert (l, t) == (left, top) and padded.shape[:2] == (ph, pw)
+        assert np.array_equal(resize_linear_u8(padded, (192, 256)), crops[i])
 
 
 def test_shard_bounds_cover_and_balance():
