@@ -12,7 +12,7 @@ HBM, + the RCCL all-gather of keypoints when N > 1) over one batch of 256 synthe
 Workload = BASELINE.json configs[1]: ViTPose-B COCO-17, batch 256, seeded random
 weights of that architecture, synthetic uniform-noise crops.
 
-Prints ONE JSON line on rank 0 with `roofline` (dominant kernel = the proj/fc2 GEMM,
+Prints ONE JSON line on rank 0 with `roofline` (dominant kernel symbol = the proj/fc2 residual GEMM,
 timed live with HIP events on the library's stream inside the timed region) and
 `cpu_baseline` (the oracle's torch-CPU per-crop path on this box's host cores, rank 0,
 N=1 only, bounded sample).
@@ -82,7 +82,7 @@ def pmc_traffic(args):
         return None
     try:
         for k, d in json.load(open(path)).items():
-            if k.startswith('gemm_kernel<F16, 1, 0') and 'hbm_bytes_per_dispatch' in d:
+            if k.startswith('gemm_kernel<F16, 2, 0') and 'hbm_bytes_per_dispatch' in d:
                 return d['hbm_bytes_per_dispatch']
     except Exception:
         pass
@@ -147,7 +147,9 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    dom = 'gemm_fc1'   # dominant kernel symbol by time (rocprofv3 stats, profiles/): the fc1 GEMM, bias+GELU epilogue
+    # dominant kernel symbol by total time (rocprofv3 --stats, profiles/r1_tuned_path_rocprofv3.txt): the GEMM with
+    # the fp32 bias+residual epilogue, launched 24x per step (attn.proj K=D and mlp.fc2 K=4D, both N=D)
+    dom = 'gemm_proj_fc2'
     eng.set_profiling([dom])
     eng.reset_profile()
     fence()
@@ -191,7 +193,7 @@ def main():
                        'gflop_per_person': round(shp.gflop_per_person(), 3)},
             'model_tflops': round(persons_s * shp.gflop_per_person() / 1e3, 1),
             'model_frac_of_mfma_peak': round(persons_s * shp.gflop_per_person() * 1e9 / PEAK_MFMA_16BIT, 4),
-            'roofline': {'bound': 'mfma', 'kernel': 'gemm_kernel<EPI_BIAS_GELU, 256x256x64 tile> (mlp.fc1 + bias + GELU, M=B*192, N=4D, K=D)',
+            'roofline': {'bound': 'mfma', 'kernel': 'gemm_kernel<F16, EPI_BIAS_RESID, A_DENSE, TileCfg<192,128,64,96,64,2,1,0>> (attn.proj + mlp.fc2: +bias +fp32 residual; flops = average of the two shapes)',
                          'achieved': round(ach / 1e12, 2), 'peak': PEAK_MFMA_16BIT / 1e12, 'unit': 'TFLOP/s',
                          'frac': round(ach / PEAK_MFMA_16BIT, 4), 'traffic': pmc_traffic(args),
                          'launches': d['launches'], 'avg_launch_ms': round(d['ms'] / max(d['launches'], 1), 5),
