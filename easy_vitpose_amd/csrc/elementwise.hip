@@ -135,6 +135,26 @@ hipError_t layernorm_launch(int dtype, const float* x, const float* gamma, const
 }
 
 
+// Fused-LayerNorm helper: the residual GEMMs leave per-(row, n-tile) partial sums; fold them in a FIXED
+// order (deterministic, unlike atomics) into (mean, rstd) per token row.
+__global__ __launch_bounds__(256) void ln_finalize_kernel(const float* __restrict__ partials, float* __restrict__ rowstat,
+                                                          int M, int tiles, float inv_d) {
+    const int m = blockIdx.x * 256 + threadIdx.x;
+    if (m >= M) return;
+    const float* p = partials + (size_t)m * tiles * 2;
+    float s1 = 0.f, s2 = 0.f;
+    for (int t = 0; t < tiles; ++t) { s1 += p[2 * t]; s2 += p[2 * t + 1]; }
+    const float mean = s1 * inv_d;
+    const float var = fmaxf(s2 * inv_d - mean * mean, 0.f);
+    rowstat[2 * (size_t)m] = mean;
+    rowstat[2 * (size_t)m + 1] = rsqrtf(var + 1e-6f);
+}
+
+hipError_t ln_finalize_launch(const float* partials, float* rowstat, int M, int tiles, int D, hipStream_t s) {
+    hipLaunchKernelGGL(ln_finalize_kernel, dim3((M + 255) / 256), dim3(256), 0, s, partials, rowstat, M, tiles, 1.0f / (float)D);
+    return hipGetLastError();
+}
+
 template <class Ty>
 __global__ void fill_random16_kernel(uint16_t* p, size_t n, uint32_t seed) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {

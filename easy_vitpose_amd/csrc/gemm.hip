@@ -74,12 +74,23 @@ template <class C, int ES> constexpr int epi_rows_per_pass() {
     return jp;
 }
 
+// sum over the 16 lanes of a DPP row (every lane receives it): quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror, row_mirror
+__device__ __forceinline__ float row16_sum(float x) {
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xF, 0xF, true));
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x4E, 0xF, 0xF, true));
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x141, 0xF, 0xF, true));
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x140, 0xF, 0xF, true));
+    return x;
+}
+
 template <int N> __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <class T, int EPI, int AMODE, class C>
+template <class T, int EPI_, int AMODE, class C>
 __global__ __launch_bounds__(C::NT, 2) void gemm_kernel(GemmArgs g) {
+    constexpr bool LN_PROD = (EPI_ == EPI_BIAS_RESID_LN || EPI_ == EPI_POS_LN);   // fused-LayerNorm producer variant
+    constexpr int EPI = LN_PROD ? EPI_ - 4 : EPI_;                                // arithmetic of the base epilogue
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tiles_n = (g.N + C::BN - 1) / C::BN;
@@ -363,6 +374,22 @@ __global__ __launch_bounds__(C::NT, 2) void gemm_kernel(GemmArgs g) {
 #pragma unroll
         for (int i = 0; i < C::TI; ++i)
             bias4[i] = (EPI == EPI_POS) ? f32x4{0.f, 0.f, 0.f, 0.f} : *(const f32x4*)(g.bias + n0 + wn * C::WN + i * 16 + fg * 4);
+        // fused LayerNorm, consumer side: per-row (mean, rstd) of this lane's TJ fragment rows
+        constexpr bool LN_CONSUMER = (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU);
+        const bool ln_in = LN_CONSUMER && g.rowstat != nullptr;
+        float ln_mean[LN_CONSUMER ? C::TJ : 1], ln_rstd[LN_CONSUMER ? C::TJ : 1];
+        f32x4 ln_s4[LN_CONSUMER ? C::TI : 1];
+        if (LN_CONSUMER && ln_in) {
+#pragma unroll
+            for (int i = 0; i < C::TI; ++i) ln_s4[i] = *(const f32x4*)(g.ln_s + n0 + wn * C::WN + i * 16 + fg * 4);
+#pragma unroll
+            for (int j = 0; j < C::TJ; ++j) {
+                int m = m0 + wm * C::WM + j * 16 + frow;
+                if (m > g.M - 1) m = g.M - 1;
+                ln_mean[j] = g.rowstat[2 * (size_t)m];
+                ln_rstd[j] = g.rowstat[2 * (size_t)m + 1];
+            }
+        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();   // every wave is done with the operand ring
 #pragma unroll
@@ -396,7 +423,13 @@ __global__ __launch_bounds__(C::NT, 2) void gemm_kernel(GemmArgs g) {
                 char* lrow = smem + ((wm * JP + jj) * 16 + frow) * ROWBYTES + (wn * C::WN + fg * 4) * ES;
 #pragma unroll
                 for (int i = 0; i < C::TI; ++i) {
-                    f32x4 v = acc[i][p * JP + jj] + bias4[i];
+                    f32x4 v = acc[i][p * JP + jj];
+                    if (LN_CONSUMER && ln_in) {   // LayerNorm folded into this GEMM: rstd * (x.W' - mean * sum_k W') + c
+                        const float mu = ln_mean[p * JP + jj], rs = ln_rstd[p * JP + jj];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = (v[r] - mu * ln_s4[i][r]) * rs;
+                    }
+                    v += bias4[i];
                     if (EPI == EPI_BIAS_GELU) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
@@ -422,15 +455,43 @@ __global__ __launch_bounds__(C::NT, 2) void gemm_kernel(GemmArgs g) {
                     const int c = tid + q * C::NT;
                     const int lr = c / CPR, ch = c - lr * CPR;
                     const int n = n0 + ch * EPC;
-                    if (orow_q[q] == (size_t)-1) continue;
                     const char* src = smem + lr * ROWBYTES + ch * 16;
-                    if (ES == 2) {
-                        const u32x4 v = *(const u32x4*)src;
-                        uint16_t* dst = (uint16_t*)g.out + orow_q[q] + n;
-                        if (n + 8 <= g.N) *(u32x4*)dst = v;
-                        else *(u32x2*)dst = u32x2{v[0], v[1]};   // N % 8 == 4 tail (N % 4 == 0 is required)
+                    if constexpr (!LN_PROD) {
+                        if (orow_q[q] == (size_t)-1) continue;
+                        if (ES == 2) {
+                            const u32x4 v = *(const u32x4*)src;
+                            uint16_t* dst = (uint16_t*)g.out + orow_q[q] + n;
+                            if (n + 8 <= g.N) *(u32x4*)dst = v;
+                            else *(u32x2*)dst = u32x2{v[0], v[1]};   // N % 8 == 4 tail (N % 4 == 0 is required)
+                        } else {
+                            *(f32x4*)((float*)g.out + orow_q[q] + n) = *(const f32x4*)src + res[q];
+                        }
                     } else {
-                        *(f32x4*)((float*)g.out + orow_q[q] + n) = *(const f32x4*)src + res[q];
+                        // fused LayerNorm, producer side: fp32 row + its 16-bit copy + partial row statistics per
+                        // 64-column granule (16 aligned lanes hold one: NT % 16 == 0).  The fixed granule makes the
+                        // statistics -- hence the results -- independent of the tile shape; the 16-lane sums are
+                        // DPP adds (quad_perm, row_half_mirror, row_mirror): no LDS traffic.
+                        const bool ok = orow_q[q] != (size_t)-1;
+                        f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+                        if (ok) {
+                            v = *(const f32x4*)src + res[q];
+                            *(f32x4*)((float*)g.out + orow_q[q] + n) = v;
+                            u32x2 o;
+                            o[0] = pack2<T>(v[0], v[1]);
+                            o[1] = pack2<T>(v[2], v[3]);
+                            *(u32x2*)(g.out16 + orow_q[q] + n) = o;
+                        }
+                        float s1 = (v[0] + v[1]) + (v[2] + v[3]);
+                        float s2 = (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+                        s1 = row16_sum(s1);
+                        s2 = row16_sum(s2);
+                        if (ok && (ch & 15) == 0) {
+                            const int wmr = lr / (JP * 16), rr = lr - wmr * (JP * 16);
+                            const size_t m = (size_t)(m0 + wmr * C::WM + p * JP * 16 + rr);
+                            float* st = g.stats_out + (m * (size_t)(g.N / 64) + (size_t)(n >> 6)) * 2;
+                            st[0] = s1;
+                            st[1] = s2;
+                        }
                     }
                 }
             }
@@ -550,14 +611,22 @@ static hipError_t dispatch(int epi, const GemmArgs& a, hipStream_t s) {
         case EPI_POS: return by_variant<T, EPI_POS, A_DENSE>(a, s);
         case EPI_DECONV: return by_variant<T, EPI_DECONV, A_DECONV>(a, s);
         case EPI_HEATMAP: return by_variant<T, EPI_HEATMAP, A_DENSE>(a, s);
+        case EPI_BIAS_RESID_LN: return by_variant<T, EPI_BIAS_RESID_LN, A_DENSE>(a, s);
+        case EPI_POS_LN: return by_variant<T, EPI_POS_LN, A_DENSE>(a, s);
     }
     return hipErrorInvalidValue;
+}
+
+int gemm_tile_bn(int variant) {
+    static const int bn[NUM_TILE_CFGS] = {Cfg0::BN, Cfg1::BN, Cfg2::BN, Cfg3::BN, Cfg4::BN, Cfg5::BN, Cfg6::BN, Cfg7::BN, Cfg8::BN, Cfg9::BN};
+    return (variant >= 0 && variant < NUM_TILE_CFGS) ? bn[variant] : 0;
 }
 
 hipError_t gemm_launch(int dtype, int epi, const GemmArgs& a, hipStream_t s) {
     if (a.K % 64 != 0 || a.M <= 0 || a.N <= 0) return hipErrorInvalidValue;
     if (epi == EPI_DECONV && (a.Cin % 64 != 0 || a.K != 4 * a.Cin)) return hipErrorInvalidValue;
     if (epi != EPI_HEATMAP && (a.N % 4 != 0 || a.ldo % 4 != 0)) return hipErrorInvalidValue;  // 8/16-byte epilogue stores
+    if ((epi == EPI_BIAS_RESID_LN || epi == EPI_POS_LN) && (a.N % 64 != 0 || !a.out16 || !a.stats_out)) return hipErrorInvalidValue;
     return dtype == DT_F16 ? dispatch<F16>(epi, a, s) : dispatch<BF16>(epi, a, s);
 }
 

@@ -17,6 +17,8 @@ enum GemmEpi {
     EPI_POS = 3,         // + aux[m % 192]    -> fp32   [M, ldo]           (patch embed; bias folded into aux)
     EPI_DECONV = 4,      // relu(+ bias)      -> 16-bit NHWC, output-parity scatter (deconv + folded BN + ReLU)
     EPI_HEATMAP = 5,     // + bias            -> fp32 NCHW heatmaps [B, Kp, 64*48]  (final 1x1 conv)
+    EPI_BIAS_RESID_LN = 6,  // EPI_BIAS_RESID + fused-LayerNorm producer outputs (out16, stats_out)
+    EPI_POS_LN = 7,         // EPI_POS        + fused-LayerNorm producer outputs
 };
 enum GemmAMode { A_DENSE = 0, A_DECONV = 1 };
 
@@ -34,11 +36,25 @@ struct GemmArgs {
     int variant;          // tile configuration (gemm.hip Cfg0..)
     int group_m;          // grouped tile order: m-tiles per group (<= 1: plain n-fastest order)
     size_t w_parity_stride;  // filled by gemm_launch
+    // ---- fused LayerNorm ----
+    // producer side (EPI_BIAS_RESID / EPI_POS): besides the fp32 row also write its 16-bit copy and the partial
+    // row statistics (sum, sum of squares) of every 64-column granule -> stats_out[(m*(N/64) + n/64)*2]
+    uint16_t* out16;
+    float* stats_out;
+    // consumer side (EPI_BIAS / EPI_BIAS_GELU): A is the UN-normalised 16-bit residual stream, W has LayerNorm's
+    // gamma folded in; the epilogue applies  v = rstd_m * (acc - mean_m * ln_s[n]) + bias[n]  with
+    // rowstat[m] = (mean, rstd), ln_s[n] = sum_k W'[n][k], bias[n] = sum_k beta_k W[n][k] + b[n]
+    const float* rowstat;
+    const float* ln_s;
     int ablate;           // profiling only (tools/gemm_ablate.py): 1 = no operand loads after the prologue, 2 = every tile loads the A rows of m-tile 0 (A L2-resident), 8 = no epilogue stores
 };
 hipError_t gemm_launch(int dtype, int epi, const GemmArgs& a, hipStream_t s);
+int gemm_tile_bn(int variant);   // BN of a tile configuration (number of n-tiles = ceil(N / BN))
 // fill a 16-bit buffer with pseudo-random values in [-1, 1) (benchmark operands)
 hipError_t fill_random16(int dtype, uint16_t* p, size_t n, uint32_t seed, hipStream_t s);
+
+// partial row statistics [M][tiles][2] (sum, sumsq) -> rowstat [M][2] (mean, rstd), LayerNorm eps 1e-6
+hipError_t ln_finalize_launch(const float* partials, float* rowstat, int M, int tiles, int D, hipStream_t s);
 
 // calibration micro-benchmarks (tools/): kind 0/1 = MFMA 16x16x32 / 32x32x16 f16 TFLOP/s, 2 = float4 copy TB/s
 hipError_t peak_bench(int kind, double* result);

@@ -49,9 +49,10 @@ uint16_t host_to_bits(float v, int dtype) {
 }
 
 struct Block {
-    float *ln1_g, *ln1_b, *ln2_g, *ln2_b;
-    uint16_t *w_qkv, *w_proj, *w_fc1, *w_fc2;
-    float *b_qkv, *b_proj, *b_fc1, *b_fc2;
+    float *ln1_g, *ln1_b, *ln2_g, *ln2_b;          // standalone-LayerNorm path only
+    uint16_t *w_qkv, *w_proj, *w_fc1, *w_fc2;      // fused path: w_qkv / w_fc1 carry LayerNorm's gamma
+    float *b_qkv, *b_proj, *b_fc1, *b_fc2;         // fused path: b_qkv / b_fc1 = W.beta + b
+    float *s_qkv, *s_fc1;                          // fused path: row sums of the (rounded) folded weights
 };
 
 }  // namespace
@@ -77,6 +78,9 @@ struct vp_ctx {
     float* x = nullptr;
     uint16_t *y = nullptr, *qkv = nullptr, *hid = nullptr, *d1 = nullptr, *d2 = nullptr;
     float *hm = nullptr, *kp = nullptr, *tok = nullptr;
+    bool fuse_ln = false;             // LayerNorm folded into the qkv / fc1 GEMMs (VP_FUSE_LN=1 enables; measured neutral at B=256)
+    uint16_t* x16 = nullptr;          // 16-bit copy of the residual stream (fused-LN GEMM operand)
+    float *ln_part = nullptr, *rowstat = nullptr;   // partial row statistics [M][D/64][2], (mean, rstd) [M][2]
     uint8_t* frame_stage = nullptr;   // device copy of the current video frame (vp_infer_frame)
     size_t frame_cap = 0;
     int32_t* cparams = nullptr;       // per-crop geometry [max_batch, 8]
@@ -133,7 +137,51 @@ int upload_mat(vp_ctx* c, uint16_t** dst, const float* src, size_t rows, size_t 
     return VP_OK;
 }
 
-size_t pad128(size_t n) { return (n + 255) / 256 * 256; }   // weight rows: multiple of the largest BN tile (256)
+float host_from_bits(uint16_t h, int dtype) {
+    uint32_t u;
+    if (dtype == vp::DT_BF16) {
+        u = (uint32_t)h << 16;
+    } else {
+        const uint32_t sign = (uint32_t)(h & 0x8000u) << 16, e = (h >> 10) & 0x1f, m = h & 0x3ffu;
+        if (e == 0) {
+            if (m == 0) u = sign;
+            else { int sh = 0; uint32_t mm = m; while (!(mm & 0x400u)) { mm <<= 1; ++sh; }
+                   u = sign | ((uint32_t)(113 - sh) << 23) | ((mm & 0x3ffu) << 13); }
+        } else if (e == 31) u = sign | 0x7f800000u | (m << 13);
+        else u = sign | ((e + 112) << 23) | (m << 13);
+    }
+    float f;
+    std::memcpy(&f, &u, 4);
+    return f;
+}
+
+size_t pad128(size_t n) { return (n + 255) / 256 * 256; }
+
+// LayerNorm folded into the following nn.Linear (y = LN(x) W^T + b):
+//   W'[n][k] = gamma[k] W[n][k] (rounded to the operand type), s[n] = sum_k W'[n][k] (of the ROUNDED values, so the
+//   identity  LN(x).W^T = rstd (x.W'^T - mean s) + c  holds exactly for what the MFMA multiplies), c[n] = sum_k beta[k] W[n][k] + b[n]
+int upload_ln_folded(vp_ctx* c, uint16_t** w_out, float** s_out, float** c_out, const float* W, const float* b,
+                     const float* gamma, const float* beta, size_t N, size_t K) {
+    const size_t rows_pad = pad128(N);
+    std::vector<uint16_t> wq(rows_pad * K, 0);
+    std::vector<float> s(rows_pad, 0.f), cc(rows_pad, 0.f);
+    for (size_t n = 0; n < N; ++n) {
+        double ss = 0.0, sc = 0.0;
+        for (size_t k = 0; k < K; ++k) {
+            const uint16_t q = host_to_bits(gamma[k] * W[n * K + k], c->dtype);
+            wq[n * K + k] = q;
+            ss += (double)host_from_bits(q, c->dtype);
+            sc += (double)beta[k] * (double)W[n * K + k];
+        }
+        s[n] = (float)ss;
+        cc[n] = (float)(sc + (double)b[n]);
+    }
+    int rc = dalloc(c, w_out, rows_pad * K);
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpy(*w_out, wq.data(), wq.size() * 2, hipMemcpyHostToDevice));
+    if ((rc = upload_f32(c, s_out, s.data(), rows_pad))) return rc;
+    return upload_f32(c, c_out, cc.data(), rows_pad);
+}   // weight rows: multiple of the largest BN tile (256)
 
 struct Lookup {
     std::unordered_map<std::string, const vp_tensor_desc*> map;
@@ -238,8 +286,16 @@ void apply_gemm_tuning(vp_ctx* c) {
             return fail((c), VP_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e__)); \
     } while (0)
 
+struct LnFuse {
+    uint16_t* out16 = nullptr;        // producer: 16-bit copy of the output rows
+    float* stats_out = nullptr;       // producer: partial row statistics
+    const float* rowstat = nullptr;   // consumer: (mean, rstd) per row
+    const float* ln_s = nullptr;      // consumer: row sums of the folded weights
+    int* tiles_out = nullptr;         // producer: number of n-tiles written per row
+};
+
 int gemm(vp_ctx* c, int fam, int epi, const uint16_t* A, const uint16_t* W, const float* bias, void* out,
-         const float* aux, int M, int N, int K, int ldo, int Hin = 0, int Win = 0, int Cin = 0) {
+         const float* aux, int M, int N, int K, int ldo, int Hin = 0, int Win = 0, int Cin = 0, const LnFuse* ln = nullptr) {
     vp::GemmArgs g{};
     g.A = A; g.W = W; g.bias = bias; g.out = out; g.aux = aux;
     g.M = M; g.N = N; g.K = K; g.ldo = ldo;
@@ -261,12 +317,19 @@ int gemm(vp_ctx* c, int fam, int epi, const uint16_t* A, const uint16_t* W, cons
         const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128) * par_;
         if (t192 < 384) { g.variant = (t128 >= 256) ? 1 : 9; g.group_m = 0; }
     }
+    if (ln) {
+        g.out16 = ln->out16; g.stats_out = ln->stats_out; g.rowstat = ln->rowstat; g.ln_s = ln->ln_s;
+        if (ln->tiles_out) *ln->tiles_out = N / 64;   // partial statistics are written per 64 columns, whatever the tile
+    }
     const double par = (epi == vp::EPI_DECONV) ? 4.0 : 1.0;
     const double flops = 2.0 * M * (double)N * K * par;
     // algorithmic HBM bytes: each operand once, output once (+ residual read)
-    const double out_b = (epi == vp::EPI_BIAS_RESID || epi == vp::EPI_POS || epi == vp::EPI_HEATMAP) ? 4.0 : 2.0;
+    const bool resid = epi == vp::EPI_BIAS_RESID || epi == vp::EPI_BIAS_RESID_LN;
+    const bool f32out = resid || epi == vp::EPI_POS || epi == vp::EPI_POS_LN || epi == vp::EPI_HEATMAP;
+    const double out_b = f32out ? 4.0 : 2.0;
     double bytes = 2.0 * M * (double)(epi == vp::EPI_DECONV ? Cin : K) + 2.0 * N * (double)K * par + out_b * M * (double)N * par;
-    if (epi == vp::EPI_BIAS_RESID) bytes += 4.0 * M * (double)N;
+    if (resid) bytes += 4.0 * M * (double)N;
+    if (epi == vp::EPI_BIAS_RESID_LN || epi == vp::EPI_POS_LN) bytes += 2.0 * M * (double)N;   // 16-bit copy for the fused LayerNorm
     LAUNCH(c, fam, flops, bytes, vp::gemm_launch(c->dtype, epi, g, c->stream));
     return VP_OK;
 }
@@ -277,6 +340,37 @@ int forward_chunk(vp_ctx* c, const void* d_crops, int fmt, int n, bool want_toke
     const double in_b = (fmt == VP_INPUT_F32_NCHW ? 4.0 : 1.0) * n * 3.0 * 256 * 192;
     LAUNCH(c, VP_PROF_IM2COL, 0.0, in_b + 2.0 * M * 768, vp::im2col_launch(c->dtype, d_crops, fmt, c->hid, n, c->stream));
     int rc;
+    if (c->fuse_ln) {
+        // LayerNorm folded into the GEMMs on both sides of it: every producer of the residual stream (patch embed,
+        // attn.proj, mlp.fc2) also writes its 16-bit copy + partial row statistics; a tiny kernel folds them into
+        // (mean, rstd); qkv / fc1 multiply the UN-normalised rows by gamma-folded weights and normalise in their
+        // epilogue.  Saves the 151 MB re-read + 75 MB write of 24 of the 25 LayerNorm passes.
+        int tiles = 0;
+        LnFuse prod; prod.out16 = c->x16; prod.stats_out = c->ln_part; prod.tiles_out = &tiles;
+        auto finalize = [&]() -> int {
+            LAUNCH(c, VP_PROF_LAYERNORM, 0.0, 8.0 * M * tiles + 8.0 * M, vp::ln_finalize_launch(c->ln_part, c->rowstat, M, tiles, D, c->stream));
+            return VP_OK;
+        };
+        if ((rc = gemm(c, VP_PROF_GEMM_PATCH, vp::EPI_POS_LN, c->hid, c->w_patch, c->b_zero, c->x, c->pos, M, D, 768, D, 0, 0, 0, &prod))) return rc;
+        if ((rc = finalize())) return rc;
+        for (int l = 0; l < c->L; ++l) {
+            const Block& b = c->blocks[l];
+            LnFuse cq; cq.rowstat = c->rowstat; cq.ln_s = b.s_qkv;
+            if ((rc = gemm(c, VP_PROF_GEMM_QKV, vp::EPI_BIAS, c->x16, b.w_qkv, b.b_qkv, c->qkv, nullptr, M, 3 * D, D, 3 * D, 0, 0, 0, &cq))) return rc;
+            LAUNCH(c, VP_PROF_ATTN, 4.0 * 192 * 192 * (double)D * n, 8.0 * M * D,
+                   vp::attention_launch(c->dtype, c->qkv, c->y, n, D, c->heads, c->stream));
+            if ((rc = gemm(c, VP_PROF_GEMM_PROJ, vp::EPI_BIAS_RESID_LN, c->y, b.w_proj, b.b_proj, c->x, c->x, M, D, D, D, 0, 0, 0, &prod))) return rc;
+            if ((rc = finalize())) return rc;
+            LnFuse c1; c1.rowstat = c->rowstat; c1.ln_s = b.s_fc1;
+            if ((rc = gemm(c, VP_PROF_GEMM_FC1, vp::EPI_BIAS_GELU, c->x16, b.w_fc1, b.b_fc1, c->hid, nullptr, M, 4 * D, D, 4 * D, 0, 0, 0, &c1))) return rc;
+            if (l + 1 < c->L) {
+                if ((rc = gemm(c, VP_PROF_GEMM_PROJ, vp::EPI_BIAS_RESID_LN, c->hid, b.w_fc2, b.b_fc2, c->x, c->x, M, D, 4 * D, D, 0, 0, 0, &prod))) return rc;
+                if ((rc = finalize())) return rc;
+            } else if ((rc = gemm(c, VP_PROF_GEMM_PROJ, vp::EPI_BIAS_RESID, c->hid, b.w_fc2, b.b_fc2, c->x, c->x, M, D, 4 * D, D))) {
+                return rc;   // last block: last_norm below is a standalone pass (deconv taps gather different rows)
+            }
+        }
+    } else {
     if ((rc = gemm(c, VP_PROF_GEMM_PATCH, vp::EPI_POS, c->hid, c->w_patch, c->b_zero, c->x, c->pos, M, D, 768, D))) return rc;
     for (int l = 0; l < c->L; ++l) {
         const Block& b = c->blocks[l];
@@ -290,6 +384,7 @@ int forward_chunk(vp_ctx* c, const void* d_crops, int fmt, int n, bool want_toke
                vp::layernorm_launch(c->dtype, c->x, b.ln2_g, b.ln2_b, c->y, nullptr, M, D, c->stream));
         if ((rc = gemm(c, VP_PROF_GEMM_FC1, vp::EPI_BIAS_GELU, c->y, b.w_fc1, b.b_fc1, c->hid, nullptr, M, 4 * D, D, 4 * D))) return rc;
         if ((rc = gemm(c, VP_PROF_GEMM_PROJ, vp::EPI_BIAS_RESID, c->hid, b.w_fc2, b.b_fc2, c->x, c->x, M, D, 4 * D, D))) return rc;
+    }
     }
     LAUNCH(c, VP_PROF_LAYERNORM, 0.0, 6.0 * M * D,
            vp::layernorm_launch(c->dtype, c->x, c->lnf_g, c->lnf_b, c->y, want_tokens ? c->tok : nullptr, M, D, c->stream));
@@ -358,6 +453,12 @@ int vp_create(vp_handle* out, const vp_config* cfg) {
     if ((rc = dalloc(c, &c->wh_stage, B * 2))) return bail(rc);
     if ((rc = dalloc(c, &c->x, M * D))) return bail(rc);
     if ((rc = dalloc(c, &c->y, M * D))) return bail(rc);
+    if (const char* f = getenv("VP_FUSE_LN")) c->fuse_ln = atoi(f) != 0;
+    if (c->fuse_ln) {
+        if ((rc = dalloc(c, &c->x16, M * D))) return bail(rc);
+        if ((rc = dalloc(c, &c->ln_part, M * (size_t)(D / 64) * 2))) return bail(rc);
+        if ((rc = dalloc(c, &c->rowstat, M * 2))) return bail(rc);
+    }
     if ((rc = dalloc(c, &c->qkv, M * 3 * D))) return bail(rc);
     if ((rc = dalloc(c, &c->hid, M * 4 * D))) return bail(rc);
     if ((rc = dalloc(c, &c->d1, B * 768 * 256))) return bail(rc);
@@ -397,16 +498,24 @@ int vp_load_weights(vp_handle c, const vp_tensor_desc* tensors, int32_t n_tensor
     for (int l = 0; l < c->L; ++l) {
         Block& b = c->blocks[l];
         const std::string pre = "backbone.blocks." + std::to_string(l) + ".";
-        if ((rc = lk.get(pre + "norm1.weight", D, &p)) || (rc = upload_f32(c, &b.ln1_g, p, D))) return rc;
-        if ((rc = lk.get(pre + "norm1.bias", D, &p)) || (rc = upload_f32(c, &b.ln1_b, p, D))) return rc;
-        if ((rc = lk.get(pre + "norm2.weight", D, &p)) || (rc = upload_f32(c, &b.ln2_g, p, D))) return rc;
-        if ((rc = lk.get(pre + "norm2.bias", D, &p)) || (rc = upload_f32(c, &b.ln2_b, p, D))) return rc;
-        if ((rc = lk.get(pre + "attn.qkv.weight", (int64_t)3 * DD, &p)) || (rc = upload_mat(c, &b.w_qkv, p, 3 * (size_t)D, D, pad128(3 * (size_t)D)))) return rc;
-        if ((rc = lk.get(pre + "attn.qkv.bias", 3 * D, &p)) || (rc = upload_f32(c, &b.b_qkv, p, 3 * (size_t)D))) return rc;
+        const float *g1, *be1, *g2, *be2, *wq, *bq, *w1, *b1;
+        if ((rc = lk.get(pre + "norm1.weight", D, &g1)) || (rc = lk.get(pre + "norm1.bias", D, &be1)) ||
+            (rc = lk.get(pre + "norm2.weight", D, &g2)) || (rc = lk.get(pre + "norm2.bias", D, &be2)) ||
+            (rc = lk.get(pre + "attn.qkv.weight", (int64_t)3 * DD, &wq)) || (rc = lk.get(pre + "attn.qkv.bias", 3 * D, &bq)) ||
+            (rc = lk.get(pre + "mlp.fc1.weight", (int64_t)4 * DD, &w1)) || (rc = lk.get(pre + "mlp.fc1.bias", 4 * D, &b1)))
+            return rc;
+        if (c->fuse_ln) {
+            if ((rc = upload_ln_folded(c, &b.w_qkv, &b.s_qkv, &b.b_qkv, wq, bq, g1, be1, 3 * (size_t)D, D))) return rc;
+            if ((rc = upload_ln_folded(c, &b.w_fc1, &b.s_fc1, &b.b_fc1, w1, b1, g2, be2, 4 * (size_t)D, D))) return rc;
+        } else {
+            if ((rc = upload_f32(c, &b.ln1_g, g1, D)) || (rc = upload_f32(c, &b.ln1_b, be1, D)) ||
+                (rc = upload_f32(c, &b.ln2_g, g2, D)) || (rc = upload_f32(c, &b.ln2_b, be2, D)))
+                return rc;
+            if ((rc = upload_mat(c, &b.w_qkv, wq, 3 * (size_t)D, D, pad128(3 * (size_t)D))) || (rc = upload_f32(c, &b.b_qkv, bq, 3 * (size_t)D))) return rc;
+            if ((rc = upload_mat(c, &b.w_fc1, w1, 4 * (size_t)D, D, pad128(4 * (size_t)D))) || (rc = upload_f32(c, &b.b_fc1, b1, 4 * (size_t)D))) return rc;
+        }
         if ((rc = lk.get(pre + "attn.proj.weight", (int64_t)DD, &p)) || (rc = upload_mat(c, &b.w_proj, p, D, D, pad128(D)))) return rc;
         if ((rc = lk.get(pre + "attn.proj.bias", D, &p)) || (rc = upload_f32(c, &b.b_proj, p, D))) return rc;
-        if ((rc = lk.get(pre + "mlp.fc1.weight", (int64_t)4 * DD, &p)) || (rc = upload_mat(c, &b.w_fc1, p, 4 * (size_t)D, D, pad128(4 * (size_t)D)))) return rc;
-        if ((rc = lk.get(pre + "mlp.fc1.bias", 4 * D, &p)) || (rc = upload_f32(c, &b.b_fc1, p, 4 * (size_t)D))) return rc;
         if ((rc = lk.get(pre + "mlp.fc2.weight", (int64_t)4 * DD, &p)) || (rc = upload_mat(c, &b.w_fc2, p, D, 4 * (size_t)D, pad128(D)))) return rc;
         if ((rc = lk.get(pre + "mlp.fc2.bias", D, &p)) || (rc = upload_f32(c, &b.b_fc2, p, D))) return rc;
     }

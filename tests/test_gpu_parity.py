@@ -223,3 +223,38 @@ def test_device_crop_prep_bit_exact_and_frame_entry():
     b = eng.infer(host, p[:, 6:8])
     assert np.array_equal(a, b)
     eng.close()
+
+
+def test_fused_layernorm_matches_standalone_layernorm(monkeypatch):
+    """LayerNorm folded into the qkv / fc1 GEMMs (default) vs the standalone LayerNorm kernel: same network,
+    different rounding points -- both must sit within the fp16 error budget of the oracle, and close to each other.
+    Also exercises rows with a large common-mode offset (the fold rounds x BEFORE the mean is removed)."""
+    shp, sd, sdt = weights('s', 'coco')
+    crops = synthetic_crops(4, 9, 'noise')
+    ref = oracle_heatmaps('s', 'coco', crops)
+    out = {}
+    for flag in ('1', '0'):
+        monkeypatch.setenv('VP_FUSE_LN', flag)
+        eng = VitPoseHip(shp, sd, dtype='fp16', max_batch=4)
+        out[flag] = eng.heatmaps(crops)
+        assert np.array_equal(out[flag], eng.heatmaps(crops))          # deterministic (no atomics in the statistics)
+        eng.close()
+    for flag, hm in out.items():
+        e = np.abs(hm - ref)
+        print(f'fuse_ln={flag}: max|err| {e.max():.3e} rms {np.sqrt((e ** 2).mean()):.3e}')
+        assert e.max() < HM_MAX_ERR['fp16'] and np.sqrt((e ** 2).mean()) < HM_RMS_ERR['fp16']
+    assert np.abs(out['1'] - out['0']).max() < 2e-3
+    # common-mode stress: shift the positional embedding so every token row has mean ~ 3 x its std
+    sd2 = dict(sd)
+    sd2['backbone.pos_embed'] = sd['backbone.pos_embed'] + np.float32(2.0)
+    import torch
+    sdt2 = O.to_torch_state_dict(sd2)
+    x = np.concatenate([O.pre_img(c)[0] for c in crops])
+    ref2 = O.model_forward(sdt2, x, shp.depth, shp.num_heads)
+    for flag in ('1', '0'):
+        monkeypatch.setenv('VP_FUSE_LN', flag)
+        eng = VitPoseHip(shp, sd2, dtype='fp16', max_batch=4)
+        e = np.abs(eng.heatmaps(crops) - ref2)
+        print(f'common-mode offset, fuse_ln={flag}: max|err| {e.max():.3e} rms {np.sqrt((e ** 2).mean()):.3e}')
+        assert e.max() < 3 * HM_MAX_ERR['fp16']
+        eng.close()
