@@ -213,7 +213,27 @@ __global__ __launch_bounds__(256) void peak_copy_kernel(const f32x4* __restrict_
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) out[i] = in[i];
 }
 
-// kind 0: MFMA 16x16x32 f16, 1: MFMA 32x32x16 f16 (returns TFLOP/s); 2: float4 copy (returns TB/s read+write)
+// LDS-DMA ceiling: every wave streams 1 KiB pieces global -> LDS (global_load_lds_dwordx4) from an L2-resident
+// source, DEPTH pieces in flight, nothing else.  blocks_per_cu x 256 threads, 64 KiB LDS ring per block.
+template <int DEPTH>
+__global__ __launch_bounds__(256) void peak_glds_kernel(const char* __restrict__ src, size_t src_bytes, int iters, float* sink) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const size_t stride = (size_t)gridDim.x * 4 * 1024;
+    size_t off = ((size_t)blockIdx.x * 4 + wave) * 1024;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) {
+            glds16(src + (off & (src_bytes - 1)) + lane * 16, smem + ((wave * DEPTH + d) & 63) * 1024);   // src_bytes is a power of two
+            off += stride;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    if (iters < 0) sink[threadIdx.x] = ((float*)smem)[threadIdx.x];
+}
+
+// kind 0: MFMA 16x16x32 f16, 1: MFMA 32x32x16 f16 (returns TFLOP/s); 2: float4 copy (returns TB/s read+write);
+// 3 / 4 / 5 / 6: LDS-DMA stream from a 32 MiB / 1 GiB / 2 MiB / 256 KiB source, 2 blocks per CU (TB/s into LDS)
 hipError_t peak_bench(int kind, double* result) {
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
@@ -233,6 +253,22 @@ hipError_t peak_bench(int kind, double* result) {
         const double flops = (double)blocks * 4 * iters * (kind == 0 ? 16.0 * 16384 : 4.0 * 32768);
         *result = flops / (ms * 1e-3) / 1e12;
         hipFree(d);
+    } else if (kind >= 3 && kind <= 6) {
+        const size_t bytes = kind == 3 ? ((size_t)32 << 20) : kind == 4 ? ((size_t)1 << 30) : kind == 5 ? ((size_t)2 << 20) : ((size_t)256 << 10);
+        char* a; float* d;
+        hipMalloc(&a, bytes); hipMalloc(&d, 4096);
+        hipMemset(a, 1, bytes);
+        const int iters = 2000, blocks = 512, depth = 10;
+        hipFuncSetAttribute((const void*)peak_glds_kernel<10>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+        for (int rep = 0; rep < 2; ++rep) {
+            hipEventRecord(e0, nullptr);
+            hipLaunchKernelGGL(peak_glds_kernel<10>, dim3(blocks), dim3(256), 65536, nullptr, a, bytes, iters, d);
+            hipEventRecord(e1, nullptr);
+            hipDeviceSynchronize();
+        }
+        hipEventElapsedTime(&ms, e0, e1);
+        *result = (double)blocks * 4 * depth * 1024.0 * iters / (ms * 1e-3) / 1e12;
+        hipFree(a); hipFree(d);
     } else {
         const size_t n = (size_t)1 << 26;   // 64 Mi float4 = 1 GiB
         f32x4 *a, *b;

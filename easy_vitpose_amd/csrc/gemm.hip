@@ -24,6 +24,8 @@
 //    output-parity classes, each a GEMM with K = 4*Cin whose A rows are gathered
 //    (one row chunk per k-step, zero row at the border) straight by the
 //    global_load_lds source addresses -- no im2col buffer in HBM.
+#include <utility>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -83,8 +85,59 @@ __device__ __forceinline__ float row16_sum(float x) {
     return x;
 }
 
+// ---- hand-scheduled fragment pipeline (PIPE 5): ds_read_b128 issued by inline asm so that hipcc does not
+// track them (it otherwise waits lgkmcnt(0) for a whole burst); completion is waited for with COUNTED
+// s_waitcnt lgkmcnt(N) placed by hand, each followed by sched_barrier(0) so no MFMA is hoisted above its wait.
+template <int OFF> __device__ __forceinline__ void lds_read_b128(u32x4& d, uint32_t addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF));
+}
+template <int N> __device__ __forceinline__ void wait_lgkm() {
+    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N));
+    __builtin_amdgcn_sched_barrier(0);
+}
+template <int ROWB, int... Is>
+__device__ __forceinline__ void lds_read_frags(u32x4* d, uint32_t addr, std::integer_sequence<int, Is...>) {
+    (lds_read_b128<Is * 16 * ROWB>(d[Is], addr), ...);
+}
+
 template <int N> __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// read number RI (0 .. R-1) of k-half 1: weight fragment RI, or activation fragment RI - TI
+template <class C, int RI>
+__device__ __forceinline__ void pipe5_issue(u32x4* f1, uint32_t wa1, uint32_t aa1) {
+    if constexpr (RI < C::TI) lds_read_b128<RI * 16 * C::ROWB>(f1[RI], wa1);
+    else if constexpr (RI < C::TI + C::TJ) lds_read_b128<(RI - C::TI) * 16 * C::ROWB>(f1[RI], aa1);
+}
+
+// k-half 0, group J: wait for activation fragment J, TI MFMAs, then issue reads 2J and 2J+1 of k-half 1
+template <class T, class C, int J>
+__device__ __forceinline__ void pipe5_half0(f32x4 (&acc)[C::TI][C::TJ], u32x4* f0, u32x4* f1, uint32_t wa1, uint32_t aa1) {
+    if constexpr (J < C::TJ) {
+        constexpr int R = C::TI + C::TJ;
+        constexpr int issued = R + (2 * J < R ? 2 * J : R);
+        wait_lgkm<issued - (C::TI + J + 1)>();
+#pragma unroll
+        for (int i = 0; i < C::TI; ++i) acc[i][J] = mfma16<T>(f0[i], f0[C::TI + J], acc[i][J]);
+        __builtin_amdgcn_sched_barrier(0);
+        pipe5_issue<C, 2 * J>(f1, wa1, aa1);
+        pipe5_issue<C, 2 * J + 1>(f1, wa1, aa1);
+        __builtin_amdgcn_sched_barrier(0);
+        pipe5_half0<T, C, J + 1>(acc, f0, f1, wa1, aa1);
+    }
+}
+
+// k-half 1, group J: every read is issued; fragment TI + J is complete once TJ - J - 1 younger reads remain
+template <class T, class C, int J>
+__device__ __forceinline__ void pipe5_half1(f32x4 (&acc)[C::TI][C::TJ], u32x4* f1) {
+    if constexpr (J < C::TJ) {
+        wait_lgkm<C::TJ - J - 1>();
+#pragma unroll
+        for (int i = 0; i < C::TI; ++i) acc[i][J] = mfma16<T>(f1[i], f1[C::TI + J], acc[i][J]);
+        __builtin_amdgcn_sched_barrier(0);
+        pipe5_half1<T, C, J + 1>(acc, f1);
+    }
 }
 
 template <class T, int EPI_, int AMODE, class C>
@@ -305,7 +358,24 @@ __global__ __launch_bounds__(C::NT, 2) void gemm_kernel(GemmArgs g) {
         asm volatile("" ::: "memory");
         if (kt + C::STAGES - 1 < nk && !(g.ablate & 1)) stage(kt + C::STAGES - 1, pbuf);
         const char* sb = smem + buf * C::STAGE_BYTES;
-        if (C::PIPE && C::KK == 2) {
+        if constexpr (C::PIPE == 5) {
+            // reads: per k-half wf[0..TI-1] then af[0..TJ-1] (R = TI + TJ); k-half 0 is issued up front, two
+            // reads of k-half 1 after each MFMA group of k-half 0.  Group (kk, j) = TI MFMAs wf[kk][*] x af[kk][j];
+            // it needs read TI + j of its half, so before it the allowed outstanding count is
+            //   half 0: R + min(R, 2j) - (TI + j + 1)        half 1: TJ - j - 1
+            static_assert(C::KK == 2 && C::TI + C::TJ <= 12 && 2 * C::TJ >= C::TI + C::TJ, "PIPE 5 schedule");
+            constexpr int R = C::TI + C::TJ;
+            u32x4 f0[R], f1[R];                       // [0, TI): weight fragments, [TI, R): activation fragments
+            const uint32_t lb = (uint32_t)(size_t)(lds_ptr_t)(smem) + buf * C::STAGE_BYTES;
+            const uint32_t wa0 = lb + woff, wa1 = lb + (woff ^ 64), aa0 = lb + aoff, aa1 = lb + (aoff ^ 64);
+            lds_read_frags<C::ROWB>(f0, wa0, std::make_integer_sequence<int, C::TI>{});
+            lds_read_frags<C::ROWB>(f0 + C::TI, aa0, std::make_integer_sequence<int, C::TJ>{});
+            __builtin_amdgcn_s_setprio(1);
+            __builtin_amdgcn_sched_barrier(0);
+            pipe5_half0<T, C, 0>(acc, f0, f1, wa1, aa1);
+            pipe5_half1<T, C, 0>(acc, f1);
+            __builtin_amdgcn_s_setprio(0);
+        } else if (C::PIPE && C::KK == 2) {
             // software pipelined fragment reads: the ds_reads of k-half 1 are issued between the two MFMA
             // blocks of k-half 0 and complete in their shadow (lgkmcnt is only 4 bits wide, so no more than
             // one half's reads are outstanding at a wait); sched_barriers pin this order for the compiler.
@@ -552,7 +622,9 @@ __global__ __launch_bounds__(C::NT, 2) void gemm_kernel(GemmArgs g) {
 // evenly over 256 CUs x 2 resident blocks for every encoder GEMM (no tail wave), and the epilogue of one
 // block overlaps the main loop of its CU partner.  The others are kept as measured alternatives:
 // 256x256 halves the L2->LDS operand traffic but runs 1 block / CU (epilogue exposed, tail wave at N = D);
-// Cfg6 is the staggered two-group (anti-phase wave pairs) schedule; Cfg5 the fragment-store A/B reference.
+// Cfg6 is the staggered two-group (anti-phase wave pairs) schedule; Cfg5 the fragment-store A/B reference;
+// Cfg10 = Cfg8 with hand-scheduled inline-asm ds_reads and counted lgkmcnt (bare loop +7 %, end to end +0-2 %:
+// the operand stream, not the intra-wave schedule, is what bounds these GEMMs).
 //                    BM   BN  BK   WM  WN  STAGES PIPE DIRECT      LDS   waves
 using Cfg0 = TileCfg<128, 128, 64, 64, 64, 2, 0, 0>;    //  64 KiB   4   (2 blocks / CU)
 using Cfg1 = TileCfg<128, 128, 64, 64, 64, 2, 1, 0>;    //  same + pipelined fragment reads
@@ -564,7 +636,8 @@ using Cfg6 = TileCfg<256, 256, 32, 128, 64, 4, 3, 0>;   // 128 KiB   8   stagger
 using Cfg7 = TileCfg<192, 256, 64, 96, 64, 2, 1, 0>;    // 112 KiB   8   (1 block / CU)
 using Cfg8 = TileCfg<192, 128, 64, 96, 64, 2, 1, 0>;    //  80 KiB   4   (2 blocks / CU)  <- default
 using Cfg9 = TileCfg<64, 64, 64, 32, 32, 2, 0, 0>;      //  32 KiB   4   (5 blocks / CU)  small batches: enough tiles to fill 256 CUs
-static constexpr int NUM_TILE_CFGS = 10;
+using Cfg10 = TileCfg<192, 128, 64, 96, 64, 2, 5, 0>;   //  Cfg8 with the hand-scheduled (inline-asm ds_read, counted lgkmcnt) fragment pipeline
+static constexpr int NUM_TILE_CFGS = 11;
 
 template <class T, int EPI, int AMODE, class C>
 static hipError_t launch(const GemmArgs& a, hipStream_t s) {
@@ -598,6 +671,7 @@ static hipError_t by_variant(const GemmArgs& a, hipStream_t s) {
         case 7: return launch<T, EPI, AMODE, Cfg7>(a, s);
         case 8: return launch<T, EPI, AMODE, Cfg8>(a, s);
         case 9: return launch<T, EPI, AMODE, Cfg9>(a, s);
+        case 10: return launch<T, EPI, AMODE, Cfg10>(a, s);
     }
     return hipErrorInvalidValue;
 }
@@ -618,7 +692,7 @@ static hipError_t dispatch(int epi, const GemmArgs& a, hipStream_t s) {
 }
 
 int gemm_tile_bn(int variant) {
-    static const int bn[NUM_TILE_CFGS] = {Cfg0::BN, Cfg1::BN, Cfg2::BN, Cfg3::BN, Cfg4::BN, Cfg5::BN, Cfg6::BN, Cfg7::BN, Cfg8::BN, Cfg9::BN};
+    static const int bn[NUM_TILE_CFGS] = {Cfg0::BN, Cfg1::BN, Cfg2::BN, Cfg3::BN, Cfg4::BN, Cfg5::BN, Cfg6::BN, Cfg7::BN, Cfg8::BN, Cfg9::BN, Cfg10::BN};
     return (variant >= 0 && variant < NUM_TILE_CFGS) ? bn[variant] : 0;
 }
 

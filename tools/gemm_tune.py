@@ -17,7 +17,7 @@ ap.add_argument('--batch', type=int, default=256)
 ap.add_argument('--variant', default='b')
 ap.add_argument('--dtype', default='fp16')
 ap.add_argument('--iters', type=int, default=6)
-ap.add_argument('--cfgs', default='0,1,2,3,4,5,6,7,8,9')
+ap.add_argument('--cfgs', default='0,1,2,3,4,5,6,7,8,9,10')
 ap.add_argument('--groups', default='0,8')
 args = ap.parse_args()
 lib = capi.load_library()
