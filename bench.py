@@ -101,6 +101,7 @@ def main():
     ap.add_argument('--input', default='f32', choices=['f32', 'u8'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--breakdown', action='store_true', help='extra untimed pass with every kernel family timed (stderr)')
+    ap.add_argument('--force-dist', action='store_true', help='run the RCCL code path (process group, all-gather, barrier) even with one rank')
     args = ap.parse_args()
 
     import torch
@@ -116,8 +117,10 @@ def main():
     assert torch.cuda.is_available(), 'bench.py needs an AMD GPU (the HIP path has no CPU fallback)'
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29517')
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
 
     shp = model_shape(args.variant, args.dataset)
@@ -131,18 +134,18 @@ def main():
         x = ((crops_u8.astype(np.float64) / 255 - mean) / std).transpose(0, 3, 1, 2).astype(np.float32)
         d_crops = torch.from_numpy(np.ascontiguousarray(x)).to(dev)
     d_out = torch.zeros((B, K, 3), dtype=torch.float32, device=dev)
-    d_all = torch.zeros((world * B, K, 3), dtype=torch.float32, device=dev) if world > 1 else None
+    d_all = torch.zeros((world * B, K, 3), dtype=torch.float32, device=dev) if use_dist else None
     torch.cuda.synchronize()
 
     def step():
-        eng.infer_device(d_crops, d_out, sync=(world > 1))   # library stream; sync hands over to torch's stream
-        if world > 1:
+        eng.infer_device(d_crops, d_out, sync=use_dist)      # library stream; sync hands over to torch's stream
+        if use_dist:
             dist.all_gather_into_tensor(d_all, d_out)        # RCCL over xGMI, [world*B, K, 3]
 
     def fence():
         eng.synchronize()
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
 
     for _ in range(args.warmup):
@@ -160,10 +163,12 @@ def main():
     dt = time.perf_counter() - t0
     prof = eng.profile()
     eng.set_profiling(False)
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        # every rank holds every rank's keypoints, own shard bit-identical to the local result
+        assert torch.equal(d_all[rank * B:(rank + 1) * B], d_out), 'all-gather result differs from the local shard'
     assert torch.isfinite(d_out).all(), 'non-finite keypoints'
 
     breakdown = None
@@ -188,7 +193,7 @@ def main():
             'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
             'config': {'workload': f'ViTPose-{args.variant.upper()} {args.dataset} K={K}, batch {B} x 256x192 crops per GPU '
                                    f'({args.input} input resident in HBM) -> (y,x,conf) keypoints in HBM'
-                                   + (', RCCL all-gather of keypoints' if world > 1 else ''),
+                                   + (', RCCL all-gather of keypoints' if use_dist else ''),
                        'global_batch': world * B, 'weights': 'seeded random init (no checkpoint offline)',
                        'gflop_per_person': round(shp.gflop_per_person(), 3)},
             'model_tflops': round(persons_s * shp.gflop_per_person() / 1e3, 1),
@@ -205,7 +210,7 @@ def main():
             line['cpu_baseline'] = None
         print(json.dumps(line), flush=True)
     eng.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
