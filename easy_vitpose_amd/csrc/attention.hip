@@ -61,36 +61,25 @@ __global__ __launch_bounds__(256, QT == 3 ? 2 : 3) void attention_kernel(const u
     const uint16_t* kbase = qbase + D;
     const uint16_t* vbase = qbase + 2 * D;
 
-    // ---- stage K (row major, zero padded to HDP) and V (row-major sub-tiles) into LDS ----
+    // ---- global loads first (K, Q, then V), LDS writes as the data arrives: K is written and made visible before
+    //      V has to be there, so the first QK^T + softmax run in the shadow of the V loads ----
     constexpr int CH = HD / 8;          // 16-B chunks per row
     constexpr int CHP = C::HDP / 8;
-    for (int c = tid; c < T * CHP; c += 256) {
-        const int key = c / CHP, ch = c % CHP;
-        u32x4 v = u32x4{0, 0, 0, 0};
-        if (ch < CH) v = *(const u32x4*)(kbase + (size_t)key * ld + ch * 8);
-        const int slot = C::KSWZ ? (ch ^ ((key >> 1) & 7)) : ch;
-        *(u32x4*)(Ks + key * C::KSTR + slot * 16) = v;
-    }
-    for (int c = tid; c < T * CH; c += 256) {
-        const int key = c / CH, ch = c % CH;
-        const u32x4 v = *(const u32x4*)(vbase + (size_t)key * ld + ch * 8);
-        if constexpr (C::PAIR) {       // d = 8 ch .. +3 -> sub-tile 2(ch/4), d + 4 .. +7 -> sub-tile 2(ch/4) + 1, column chunk ch%4
-            char* dst = Vs + (2 * (ch >> 2)) * C::VSUB + key * 32 + (ch & 3) * 8;
-            *(u32x2*)(dst) = u32x2{v[0], v[1]};
-            *(u32x2*)(dst + C::VSUB) = u32x2{v[2], v[3]};
-        } else {
-            *(u32x4*)(Vs + (ch >> 1) * C::VSUB + key * 32 + (ch & 1) * 16) = v;
-        }
-    }
-
-    // ---- Q fragments (B operand: lane holds Q[q = lane&15][d = kk*32 + (lane>>4)*8 .. +7]) ----
-    // A wave owns 3 query tiles, processed QT at a time: QT = 3 shares every K / V^T fragment read between the
-    // tiles (fewest LDS reads, > 200 VGPRs -> 2 blocks/CU); QT = 1 keeps one tile live (~100 VGPRs -> 3 blocks/CU,
-    // more loads in flight while other blocks compute: measured 8 % faster at B = 256).
+    constexpr int NKL = (T * CHP + 255) / 256, NVL = (T * CH + 255) / 256;
     const int fr = lane & 15, fg = lane >> 4;
     constexpr int KS = C::HDP / 32;     // k steps of QK^T
     constexpr int DT = C::DT;
-    u32x4 qf_all[3][KS];
+    u32x4 kreg[NKL], vreg[NVL], qf_all[3][KS];
+#pragma unroll
+    for (int i = 0; i < NKL; ++i) {
+        const int c = tid + i * 256, key = c / CHP, ch = c % CHP;
+        kreg[i] = u32x4{0, 0, 0, 0};
+        if (c < T * CHP && ch < CH) kreg[i] = *(const u32x4*)(kbase + (size_t)key * ld + ch * 8);
+    }
+    // Q fragments (B operand: lane holds Q[q = lane&15][d = kk*32 + (lane>>4)*8 .. +7]).  A wave owns 3 query
+    // tiles, processed QT at a time: QT = 3 shares every K / V^T fragment read between the tiles (fewest LDS reads,
+    // > 200 VGPRs -> 2 blocks/CU); QT = 1 keeps one tile live (~100 VGPRs -> 3 blocks/CU, more loads in flight
+    // while other blocks compute: measured 8 % faster at B = 256).
 #pragma unroll
     for (int t = 0; t < 3; ++t) {
         const int q = (wave * 3 + t) * 16 + fr;
@@ -100,7 +89,34 @@ __global__ __launch_bounds__(256, QT == 3 ? 2 : 3) void attention_kernel(const u
             qf_all[t][kk] = (d < HD) ? *(const u32x4*)(qbase + (size_t)q * ld + d) : u32x4{0, 0, 0, 0};
         }
     }
+#pragma unroll
+    for (int i = 0; i < NVL; ++i) {
+        const int c = tid + i * 256, key = c / CH, ch = c % CH;
+        if (c < T * CH) vreg[i] = *(const u32x4*)(vbase + (size_t)key * ld + ch * 8);
+    }
+#pragma unroll
+    for (int i = 0; i < NKL; ++i) {
+        const int c = tid + i * 256, key = c / CHP, ch = c % CHP;
+        const int slot = C::KSWZ ? (ch ^ ((key >> 1) & 7)) : ch;
+        if (c < T * CHP) *(u32x4*)(Ks + key * C::KSTR + slot * 16) = kreg[i];
+    }
     __syncthreads();
+    auto store_v = [&]() {
+#pragma unroll
+        for (int i = 0; i < NVL; ++i) {
+            const int c = tid + i * 256, key = c / CH, ch = c % CH;
+            if (c >= T * CH) continue;
+            const u32x4 v = vreg[i];
+            if constexpr (C::PAIR) {   // d = 8 ch .. +3 -> sub-tile 2(ch/4), d + 4 .. +7 -> sub-tile 2(ch/4) + 1, column chunk ch%4
+                char* dst = Vs + (2 * (ch >> 2)) * C::VSUB + key * 32 + (ch & 3) * 8;
+                *(u32x2*)(dst) = u32x2{v[0], v[1]};
+                *(u32x2*)(dst + C::VSUB) = u32x2{v[2], v[3]};
+            } else {
+                *(u32x4*)(Vs + (ch >> 1) * C::VSUB + key * 32 + (ch & 1) * 16) = v;
+            }
+        }
+        __syncthreads();
+    };
 
     // per-lane LDS bases: K fragment row fr (+16 kt), slot kk*4+fg; V transpose read: lane (4 j + m) of a 16-lane
     // group supplies the address of (key 4 g + j, column chunk m) and receives column fr of keys 4 g .. 4 g + 3
@@ -161,6 +177,7 @@ __global__ __launch_bounds__(256, QT == 3 ? 2 : 3) void attention_kernel(const u
         }
 
         // ---- O^T[d][q] = sum_key V^T[d][key] P^T[key][q], sub-tile (pair) at a time ----
+        if (t0 == 0) store_v();
         constexpr int G = C::PAIR ? 2 : 1;
 #pragma unroll
         for (int dp = 0; dp < DT; dp += G) {

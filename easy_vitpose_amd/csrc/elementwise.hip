@@ -69,10 +69,11 @@ hipError_t im2col_launch(int dtype, const void* crops, int fmt, uint16_t* out, i
 // nn.LayerNorm(eps=1e-6) (vit.py:274) over the fp32 residual stream, one wave per
 // token row, row held in registers (D <= 1280 -> <= 5 float4 per lane), two-pass
 // mean / variance in fp32, output rounded once to the GEMM operand type.
-template <class Ty>
+// PLANES: x is the two-plane 16-bit residual stream of the fused-LayerNorm path (x = hi + lo, gemm.hip).
+template <class Ty, bool PLANES>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, uint16_t* __restrict__ out16,
-                                                        float* __restrict__ out32, int M, int D) {
+                                                        float* __restrict__ out32, int M, int D, size_t plane) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
@@ -85,7 +86,17 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
         const int idx = lane + 64 * i;
         v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (idx < nv) {
-            v[i] = xr[idx];
+            if constexpr (PLANES) {
+                const uint16_t* xh = (const uint16_t*)x + (size_t)row * D;
+                const u32x2 h = ((const u32x2*)xh)[idx], l = ((const u32x2*)(xh + plane))[idx];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int sh = (e & 1) * 16;
+                    v[i][e] = from_bits<Ty>((uint16_t)(h[e >> 1] >> sh)) + from_bits<Ty>((uint16_t)(l[e >> 1] >> sh));
+                }
+            } else {
+                v[i] = xr[idx];
+            }
             sum += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
         }
     }
@@ -124,13 +135,13 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 }
 
 hipError_t layernorm_launch(int dtype, const float* x, const float* gamma, const float* beta, uint16_t* out16,
-                            float* out32, int M, int D, hipStream_t s) {
+                            float* out32, int M, int D, hipStream_t s, size_t plane) {
     if ((D & 3) || D > 1280) return hipErrorInvalidValue;
     const int grid = (M + 3) / 4;
-    if (dtype == DT_F16)
-        hipLaunchKernelGGL(layernorm_kernel<F16>, dim3(grid), dim3(256), 0, s, x, gamma, beta, out16, out32, M, D);
-    else
-        hipLaunchKernelGGL(layernorm_kernel<BF16>, dim3(grid), dim3(256), 0, s, x, gamma, beta, out16, out32, M, D);
+#define VP_LN(TY, PL) hipLaunchKernelGGL((layernorm_kernel<TY, PL>), dim3(grid), dim3(256), 0, s, x, gamma, beta, out16, out32, M, D, plane)
+    if (dtype == DT_F16) { if (plane) VP_LN(F16, true); else VP_LN(F16, false); }
+    else { if (plane) VP_LN(BF16, true); else VP_LN(BF16, false); }
+#undef VP_LN
     return hipGetLastError();
 }
 

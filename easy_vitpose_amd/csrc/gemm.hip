@@ -85,6 +85,21 @@ __device__ __forceinline__ float row16_sum(float x) {
     return x;
 }
 
+// sum over the 8 lanes of a DPP half-row (every lane receives it): quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror
+__device__ __forceinline__ float row8_sum(float x) {
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xF, 0xF, true));
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x4E, 0xF, 0xF, true));
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x141, 0xF, 0xF, true));
+    return x;
+}
+
+// fused-LayerNorm producer: as epi_rows_per_pass<C, 4>, leaving room for the tile's row statistics behind the staged rows
+template <class C> constexpr int epi_rows_per_pass_ln() {
+    int jp = C::TJ;
+    while (jp > 1 && C::NWM * jp * 16 * (C::BN * 4 + 16) + C::BM * (C::BN / 64) * 8 > C::LDS) jp /= 2;
+    return jp;
+}
+
 // ---- hand-scheduled fragment pipeline (PIPE 5): ds_read_b128 issued by inline asm so that hipcc does not
 // track them (it otherwise waits lgkmcnt(0) for a whole burst); completion is waited for with COUNTED
 // s_waitcnt lgkmcnt(N) placed by hand, each followed by sched_barrier(0) so no MFMA is hoisted above its wait.
@@ -431,7 +446,124 @@ __global__ __launch_bounds__(C::NT, 2) void gemm_kernel(GemmArgs g) {
     // stride: measured 1.2-1.7 TB/s.  Instead the C tile goes through the (now idle) LDS ring in passes
     // of JP row-tiles per wave and leaves as whole-row 16-byte-per-lane accesses (a wave instruction =
     // 1 KiB of consecutive output bytes); the fp32 residual / pos operand is read the same way.
-    if constexpr (EPI != EPI_HEATMAP && !C::DIRECT) {
+    if constexpr (LN_PROD && !C::DIRECT) {
+        // Fused-LayerNorm producer (patch embed, attn.proj, mlp.fc2).  The residual stream lives in HBM as two
+        // 16-bit planes, x = hi + lo with hi = round16(x), lo = round16(x - hi): the same 4 bytes per element as
+        // fp32 (>= 22 significant bits), but the hi plane IS the un-normalised 16-bit operand the next qkv / fc1
+        // GEMM reads, so the fusion needs no extra copy.  Rows leave the LDS staging as 8-element chunks: two
+        // 16-byte plane loads (residual) and two 16-byte plane stores per lane -- the same instruction count as
+        // the fp32 epilogue.  Partial row statistics (sum, sum of squares) are taken per 64-column granule = 8
+        // aligned lanes (DPP adds, fixed order: independent of the tile shape, hence of the batch size), parked in
+        // LDS and written once per tile.
+        constexpr int ROWBYTES = C::BN * 4 + 16;
+        constexpr int JP = epi_rows_per_pass_ln<C>();
+        constexpr int CR = C::NWM * JP * 16;          // rows staged per pass
+        constexpr int CPR = C::BN / 8;                // 8-element chunks per row
+        constexpr int NCH = CR * CPR / C::NT;         // chunks per thread per pass
+        constexpr int GR = C::BN / 64;                // statistic granules per tile row
+        static_assert(NCH * C::NT == CR * CPR && CPR % 8 == 0 && C::NT % 8 == 0, "chunks must split evenly over threads");
+        static_assert(CR * ROWBYTES + C::BM * GR * 8 <= C::LDS, "row statistics must fit behind the staged rows");
+        float* statbuf = (float*)(smem + CR * ROWBYTES);
+        uint16_t* out_hi = (uint16_t*)g.out;
+        uint16_t* out_lo = out_hi + g.plane;
+        const uint16_t* aux_hi = (const uint16_t*)g.aux;
+        const uint16_t* aux_lo = aux_hi + g.plane;
+        f32x4 bias4[C::TI];
+#pragma unroll
+        for (int i = 0; i < C::TI; ++i)
+            bias4[i] = (EPI == EPI_POS) ? f32x4{0.f, 0.f, 0.f, 0.f} : *(const f32x4*)(g.bias + n0 + wn * C::WN + i * 16 + fg * 4);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();   // every wave is done with the operand ring
+#pragma unroll
+        for (int p = 0; p < C::TJ / JP; ++p) {
+            size_t orow_q[NCH];
+            u32x4 ra[NCH], rb[NCH];   // residual: (hi, lo) planes of 8 elements, or the 8 fp32 pos values
+#pragma unroll
+            for (int q = 0; q < NCH; ++q) {
+                const int c = tid + q * C::NT;
+                const int lr = c / CPR, ch = c - lr * CPR;
+                const int wmr = lr / (JP * 16), rr = lr - wmr * (JP * 16);
+                const int m = m0 + wmr * C::WM + p * JP * 16 + rr;
+                const int n = n0 + ch * 8;
+                orow_q[q] = (size_t)-1;
+                if (m >= g.M || n >= g.N) continue;
+                orow_q[q] = (size_t)m * g.ldo;
+                if (EPI == EPI_POS) {
+                    const float* pr = g.aux + (size_t)(m % 192) * g.ldo + n;
+                    ra[q] = *(const u32x4*)pr;
+                    rb[q] = *(const u32x4*)(pr + 4);
+                } else {
+                    ra[q] = *(const u32x4*)(aux_hi + orow_q[q] + n);
+                    rb[q] = *(const u32x4*)(aux_lo + orow_q[q] + n);
+                }
+            }
+#pragma unroll
+            for (int jj = 0; jj < JP; ++jj) {
+                char* lrow = smem + ((wm * JP + jj) * 16 + frow) * ROWBYTES + (wn * C::WN + fg * 4) * 4;
+#pragma unroll
+                for (int i = 0; i < C::TI; ++i) *(f32x4*)(lrow + i * 64) = acc[i][p * JP + jj] + bias4[i];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < NCH; ++q) {
+                const int c = tid + q * C::NT;
+                const int lr = c / CPR, ch = c - lr * CPR;
+                const bool ok = orow_q[q] != (size_t)-1;
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = 0.f;
+                if (ok) {
+                    const f32x4 s0 = *(const f32x4*)(smem + lr * ROWBYTES + ch * 32);
+                    const f32x4 s1 = *(const f32x4*)(smem + lr * ROWBYTES + ch * 32 + 16);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float st = e < 4 ? s0[e] : s1[e - 4];
+                        float r;
+                        if (EPI == EPI_POS) {
+                            r = __builtin_bit_cast(float, e < 4 ? ra[q][e] : rb[q][e - 4]);
+                        } else {
+                            const int sh = (e & 1) * 16;
+                            r = from_bits<T>((uint16_t)(ra[q][e >> 1] >> sh)) + from_bits<T>((uint16_t)(rb[q][e >> 1] >> sh));
+                        }
+                        v[e] = st + r;
+                    }
+                    u32x4 oh, ol;
+#pragma unroll
+                    for (int e = 0; e < 8; e += 2) {
+                        const uint16_t h0 = to_bits<T>(v[e]), h1 = to_bits<T>(v[e + 1]);
+                        const uint16_t l0 = to_bits<T>(v[e] - from_bits<T>(h0)), l1 = to_bits<T>(v[e + 1] - from_bits<T>(h1));
+                        oh[e >> 1] = (uint32_t)h0 | ((uint32_t)h1 << 16);
+                        ol[e >> 1] = (uint32_t)l0 | ((uint32_t)l1 << 16);
+                        // the statistics are those of the value the planes actually hold
+                        v[e] = from_bits<T>(h0) + from_bits<T>(l0);
+                        v[e + 1] = from_bits<T>(h1) + from_bits<T>(l1);
+                    }
+                    if (!(g.ablate & 8)) {
+                        *(u32x4*)(out_hi + orow_q[q] + n0 + ch * 8) = oh;
+                        *(u32x4*)(out_lo + orow_q[q] + n0 + ch * 8) = ol;
+                    }
+                }
+                float s1 = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+                float s2 = ((v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3])) +
+                           ((v[4] * v[4] + v[5] * v[5]) + (v[6] * v[6] + v[7] * v[7]));
+                s1 = row8_sum(s1);
+                s2 = row8_sum(s2);
+                if ((ch & 7) == 0) {
+                    const int wmr = lr / (JP * 16), rr = lr - wmr * (JP * 16);
+                    const int trow = wmr * C::WM + p * JP * 16 + rr;
+                    *(float2*)(statbuf + (trow * GR + (ch >> 3)) * 2) = float2{s1, s2};
+                }
+            }
+            if (p + 1 < C::TJ / JP) __syncthreads();
+        }
+        __syncthreads();
+        for (int t = tid; t < C::BM * GR; t += C::NT) {
+            const int trow = t / GR, gi = t - trow * GR;
+            const int m = m0 + trow, n = n0 + gi * 64;
+            if (m < g.M && n < g.N && !(g.ablate & 8))
+                *(float2*)(g.stats_out + ((size_t)m * (g.N / 64) + (n >> 6)) * 2) = *(const float2*)(statbuf + t * 2);
+        }
+    } else if constexpr (EPI != EPI_HEATMAP && !C::DIRECT) {
         constexpr int ES = (EPI == EPI_BIAS_RESID || EPI == EPI_POS) ? 4 : 2;   // bytes per staged element
         constexpr int ROWBYTES = C::BN * ES + 16;                               // +16 B: conflict-free fragment writes
         constexpr int JP = epi_rows_per_pass<C, ES>();
@@ -526,42 +658,14 @@ __global__ __launch_bounds__(C::NT, 2) void gemm_kernel(GemmArgs g) {
                     const int lr = c / CPR, ch = c - lr * CPR;
                     const int n = n0 + ch * EPC;
                     const char* src = smem + lr * ROWBYTES + ch * 16;
-                    if constexpr (!LN_PROD) {
-                        if (orow_q[q] == (size_t)-1) continue;
-                        if (ES == 2) {
-                            const u32x4 v = *(const u32x4*)src;
-                            uint16_t* dst = (uint16_t*)g.out + orow_q[q] + n;
-                            if (n + 8 <= g.N) *(u32x4*)dst = v;
-                            else *(u32x2*)dst = u32x2{v[0], v[1]};   // N % 8 == 4 tail (N % 4 == 0 is required)
-                        } else {
-                            *(f32x4*)((float*)g.out + orow_q[q] + n) = *(const f32x4*)src + res[q];
-                        }
+                    if (orow_q[q] == (size_t)-1) continue;
+                    if (ES == 2) {
+                        const u32x4 v = *(const u32x4*)src;
+                        uint16_t* dst = (uint16_t*)g.out + orow_q[q] + n;
+                        if (n + 8 <= g.N) *(u32x4*)dst = v;
+                        else *(u32x2*)dst = u32x2{v[0], v[1]};   // N % 8 == 4 tail (N % 4 == 0 is required)
                     } else {
-                        // fused LayerNorm, producer side: fp32 row + its 16-bit copy + partial row statistics per
-                        // 64-column granule (16 aligned lanes hold one: NT % 16 == 0).  The fixed granule makes the
-                        // statistics -- hence the results -- independent of the tile shape; the 16-lane sums are
-                        // DPP adds (quad_perm, row_half_mirror, row_mirror): no LDS traffic.
-                        const bool ok = orow_q[q] != (size_t)-1;
-                        f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
-                        if (ok) {
-                            v = *(const f32x4*)src + res[q];
-                            *(f32x4*)((float*)g.out + orow_q[q] + n) = v;
-                            u32x2 o;
-                            o[0] = pack2<T>(v[0], v[1]);
-                            o[1] = pack2<T>(v[2], v[3]);
-                            *(u32x2*)(g.out16 + orow_q[q] + n) = o;
-                        }
-                        float s1 = (v[0] + v[1]) + (v[2] + v[3]);
-                        float s2 = (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
-                        s1 = row16_sum(s1);
-                        s2 = row16_sum(s2);
-                        if (ok && (ch & 15) == 0) {
-                            const int wmr = lr / (JP * 16), rr = lr - wmr * (JP * 16);
-                            const size_t m = (size_t)(m0 + wmr * C::WM + p * JP * 16 + rr);
-                            float* st = g.stats_out + (m * (size_t)(g.N / 64) + (size_t)(n >> 6)) * 2;
-                            st[0] = s1;
-                            st[1] = s2;
-                        }
+                        *(f32x4*)((float*)g.out + orow_q[q] + n) = *(const f32x4*)src + res[q];
                     }
                 }
             }
@@ -641,6 +745,7 @@ static constexpr int NUM_TILE_CFGS = 11;
 
 template <class T, int EPI, int AMODE, class C>
 static hipError_t launch(const GemmArgs& a, hipStream_t s) {
+    if constexpr ((EPI == EPI_BIAS_RESID_LN || EPI == EPI_POS_LN) && C::DIRECT) return hipErrorInvalidValue;
     auto kern = gemm_kernel<T, EPI, AMODE, C>;
     static bool attr_done = false;
     if (!attr_done) {
@@ -700,7 +805,7 @@ hipError_t gemm_launch(int dtype, int epi, const GemmArgs& a, hipStream_t s) {
     if (a.K % 64 != 0 || a.M <= 0 || a.N <= 0) return hipErrorInvalidValue;
     if (epi == EPI_DECONV && (a.Cin % 64 != 0 || a.K != 4 * a.Cin)) return hipErrorInvalidValue;
     if (epi != EPI_HEATMAP && (a.N % 4 != 0 || a.ldo % 4 != 0)) return hipErrorInvalidValue;  // 8/16-byte epilogue stores
-    if ((epi == EPI_BIAS_RESID_LN || epi == EPI_POS_LN) && (a.N % 64 != 0 || !a.out16 || !a.stats_out)) return hipErrorInvalidValue;
+    if ((epi == EPI_BIAS_RESID_LN || epi == EPI_POS_LN) && (a.N % 64 != 0 || !a.plane || !a.stats_out)) return hipErrorInvalidValue;
     return dtype == DT_F16 ? dispatch<F16>(epi, a, s) : dispatch<BF16>(epi, a, s);
 }
 

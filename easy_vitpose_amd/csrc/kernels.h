@@ -17,8 +17,8 @@ enum GemmEpi {
     EPI_POS = 3,         // + aux[m % 192]    -> fp32   [M, ldo]           (patch embed; bias folded into aux)
     EPI_DECONV = 4,      // relu(+ bias)      -> 16-bit NHWC, output-parity scatter (deconv + folded BN + ReLU)
     EPI_HEATMAP = 5,     // + bias            -> fp32 NCHW heatmaps [B, Kp, 64*48]  (final 1x1 conv)
-    EPI_BIAS_RESID_LN = 6,  // EPI_BIAS_RESID + fused-LayerNorm producer outputs (out16, stats_out)
-    EPI_POS_LN = 7,         // EPI_POS        + fused-LayerNorm producer outputs
+    EPI_BIAS_RESID_LN = 6,  // EPI_BIAS_RESID on the two-plane residual stream + fused-LayerNorm row statistics
+    EPI_POS_LN = 7,         // EPI_POS        writing the two-plane residual stream + row statistics
 };
 enum GemmAMode { A_DENSE = 0, A_DECONV = 1 };
 
@@ -37,9 +37,10 @@ struct GemmArgs {
     int group_m;          // grouped tile order: m-tiles per group (<= 1: plain n-fastest order)
     size_t w_parity_stride;  // filled by gemm_launch
     // ---- fused LayerNorm ----
-    // producer side (EPI_BIAS_RESID / EPI_POS): besides the fp32 row also write its 16-bit copy and the partial
-    // row statistics (sum, sum of squares) of every 64-column granule -> stats_out[(m*(N/64) + n/64)*2]
-    uint16_t* out16;
+    // producer side (EPI_BIAS_RESID_LN / EPI_POS_LN): the residual stream is two 16-bit planes, x = hi + lo,
+    // hi = round16(x) at out / aux, lo = round16(x - hi) `plane` elements behind it; besides the rows the partial
+    // row statistics (sum, sum of squares) of every 64-column granule go to stats_out[(m*(N/64) + n/64)*2]
+    size_t plane;
     float* stats_out;
     // consumer side (EPI_BIAS / EPI_BIAS_GELU): A is the UN-normalised 16-bit residual stream, W has LayerNorm's
     // gamma folded in; the epilogue applies  v = rstd_m * (acc - mean_m * ln_s[n]) + bias[n]  with
@@ -65,9 +66,10 @@ hipError_t peak_bench(int kind, double* result);
 hipError_t attention_launch(int dtype, const uint16_t* qkv, uint16_t* out, int B, int D, int heads, hipStream_t s);
 
 // ---------------------------------------------------------------- elementwise
-// fp32 [M, D] -> LayerNorm(eps 1e-6) -> 16-bit [M, D] (out16) and/or fp32 (out32), either may be null
+// fp32 [M, D] -> LayerNorm(eps 1e-6) -> 16-bit [M, D] (out16) and/or fp32 (out32), either may be null.
+// plane != 0: x is the two-plane 16-bit residual stream (hi at x, lo `plane` elements behind) instead of fp32.
 hipError_t layernorm_launch(int dtype, const float* x, const float* gamma, const float* beta,
-                            uint16_t* out16, float* out32, int M, int D, hipStream_t s);
+                            uint16_t* out16, float* out32, int M, int D, hipStream_t s, size_t plane = 0);
 // crops -> im2col patch matrix [B*192, 768] 16-bit (k = c*256 + ky*16 + kx, zero border of 2 px)
 hipError_t im2col_launch(int dtype, const void* crops, int input_format, uint16_t* out, int B, hipStream_t s);
 

@@ -78,8 +78,7 @@ struct vp_ctx {
     float* x = nullptr;
     uint16_t *y = nullptr, *qkv = nullptr, *hid = nullptr, *d1 = nullptr, *d2 = nullptr;
     float *hm = nullptr, *kp = nullptr, *tok = nullptr;
-    bool fuse_ln = false;             // LayerNorm folded into the qkv / fc1 GEMMs (VP_FUSE_LN=1 enables; measured neutral at B=256)
-    uint16_t* x16 = nullptr;          // 16-bit copy of the residual stream (fused-LN GEMM operand)
+    bool fuse_ln = true;              // LayerNorm folded into the GEMMs on both sides of it (VP_FUSE_LN=0: standalone passes)
     float *ln_part = nullptr, *rowstat = nullptr;   // partial row statistics [M][D/64][2], (mean, rstd) [M][2]
     uint8_t* frame_stage = nullptr;   // device copy of the current video frame (vp_infer_frame)
     size_t frame_cap = 0;
@@ -287,7 +286,7 @@ void apply_gemm_tuning(vp_ctx* c) {
     } while (0)
 
 struct LnFuse {
-    uint16_t* out16 = nullptr;        // producer: 16-bit copy of the output rows
+    size_t plane = 0;                 // producer: elements between the hi and lo planes of the residual stream
     float* stats_out = nullptr;       // producer: partial row statistics
     const float* rowstat = nullptr;   // consumer: (mean, rstd) per row
     const float* ln_s = nullptr;      // consumer: row sums of the folded weights
@@ -318,7 +317,7 @@ int gemm(vp_ctx* c, int fam, int epi, const uint16_t* A, const uint16_t* W, cons
         if (t192 < 384) { g.variant = (t128 >= 256) ? 1 : 9; g.group_m = 0; }
     }
     if (ln) {
-        g.out16 = ln->out16; g.stats_out = ln->stats_out; g.rowstat = ln->rowstat; g.ln_s = ln->ln_s;
+        g.plane = ln->plane; g.stats_out = ln->stats_out; g.rowstat = ln->rowstat; g.ln_s = ln->ln_s;
         if (ln->tiles_out) *ln->tiles_out = N / 64;   // partial statistics are written per 64 columns, whatever the tile
     }
     const double par = (epi == vp::EPI_DECONV) ? 4.0 : 1.0;
@@ -329,7 +328,7 @@ int gemm(vp_ctx* c, int fam, int epi, const uint16_t* A, const uint16_t* W, cons
     const double out_b = f32out ? 4.0 : 2.0;
     double bytes = 2.0 * M * (double)(epi == vp::EPI_DECONV ? Cin : K) + 2.0 * N * (double)K * par + out_b * M * (double)N * par;
     if (resid) bytes += 4.0 * M * (double)N;
-    if (epi == vp::EPI_BIAS_RESID_LN || epi == vp::EPI_POS_LN) bytes += 2.0 * M * (double)N;   // 16-bit copy for the fused LayerNorm
+    if (epi == vp::EPI_BIAS_RESID_LN || epi == vp::EPI_POS_LN) bytes += 8.0 * M * (double)(N / 64);   // partial row statistics
     LAUNCH(c, fam, flops, bytes, vp::gemm_launch(c->dtype, epi, g, c->stream));
     return VP_OK;
 }
@@ -340,13 +339,17 @@ int forward_chunk(vp_ctx* c, const void* d_crops, int fmt, int n, bool want_toke
     const double in_b = (fmt == VP_INPUT_F32_NCHW ? 4.0 : 1.0) * n * 3.0 * 256 * 192;
     LAUNCH(c, VP_PROF_IM2COL, 0.0, in_b + 2.0 * M * 768, vp::im2col_launch(c->dtype, d_crops, fmt, c->hid, n, c->stream));
     int rc;
+    size_t plane = 0;   // != 0: the residual stream c->x is held as two 16-bit planes (fused-LayerNorm path)
     if (c->fuse_ln) {
-        // LayerNorm folded into the GEMMs on both sides of it: every producer of the residual stream (patch embed,
-        // attn.proj, mlp.fc2) also writes its 16-bit copy + partial row statistics; a tiny kernel folds them into
-        // (mean, rstd); qkv / fc1 multiply the UN-normalised rows by gamma-folded weights and normalise in their
-        // epilogue.  Saves the 151 MB re-read + 75 MB write of 24 of the 25 LayerNorm passes.
+        // LayerNorm folded into the GEMMs on both sides of it.  The residual stream is kept as two 16-bit planes
+        // (x = hi + lo, same bytes as fp32, >= 22 significant bits): every producer (patch embed, attn.proj,
+        // mlp.fc2) writes the planes + partial row statistics, a tiny kernel folds those into (mean, rstd), and
+        // qkv / fc1 multiply the hi plane -- the UN-normalised rows -- by gamma-folded weights and normalise in
+        // their epilogue.  Saves the 151 MB read + 75 MB write of 24 of the 25 LayerNorm passes.
+        plane = (size_t)M * D;
+        uint16_t* xh = (uint16_t*)c->x;
         int tiles = 0;
-        LnFuse prod; prod.out16 = c->x16; prod.stats_out = c->ln_part; prod.tiles_out = &tiles;
+        LnFuse prod; prod.plane = plane; prod.stats_out = c->ln_part; prod.tiles_out = &tiles;
         auto finalize = [&]() -> int {
             LAUNCH(c, VP_PROF_LAYERNORM, 0.0, 8.0 * M * tiles + 8.0 * M, vp::ln_finalize_launch(c->ln_part, c->rowstat, M, tiles, D, c->stream));
             return VP_OK;
@@ -356,19 +359,15 @@ int forward_chunk(vp_ctx* c, const void* d_crops, int fmt, int n, bool want_toke
         for (int l = 0; l < c->L; ++l) {
             const Block& b = c->blocks[l];
             LnFuse cq; cq.rowstat = c->rowstat; cq.ln_s = b.s_qkv;
-            if ((rc = gemm(c, VP_PROF_GEMM_QKV, vp::EPI_BIAS, c->x16, b.w_qkv, b.b_qkv, c->qkv, nullptr, M, 3 * D, D, 3 * D, 0, 0, 0, &cq))) return rc;
+            if ((rc = gemm(c, VP_PROF_GEMM_QKV, vp::EPI_BIAS, xh, b.w_qkv, b.b_qkv, c->qkv, nullptr, M, 3 * D, D, 3 * D, 0, 0, 0, &cq))) return rc;
             LAUNCH(c, VP_PROF_ATTN, 4.0 * 192 * 192 * (double)D * n, 8.0 * M * D,
                    vp::attention_launch(c->dtype, c->qkv, c->y, n, D, c->heads, c->stream));
             if ((rc = gemm(c, VP_PROF_GEMM_PROJ, vp::EPI_BIAS_RESID_LN, c->y, b.w_proj, b.b_proj, c->x, c->x, M, D, D, D, 0, 0, 0, &prod))) return rc;
             if ((rc = finalize())) return rc;
             LnFuse c1; c1.rowstat = c->rowstat; c1.ln_s = b.s_fc1;
-            if ((rc = gemm(c, VP_PROF_GEMM_FC1, vp::EPI_BIAS_GELU, c->x16, b.w_fc1, b.b_fc1, c->hid, nullptr, M, 4 * D, D, 4 * D, 0, 0, 0, &c1))) return rc;
-            if (l + 1 < c->L) {
-                if ((rc = gemm(c, VP_PROF_GEMM_PROJ, vp::EPI_BIAS_RESID_LN, c->hid, b.w_fc2, b.b_fc2, c->x, c->x, M, D, 4 * D, D, 0, 0, 0, &prod))) return rc;
-                if ((rc = finalize())) return rc;
-            } else if ((rc = gemm(c, VP_PROF_GEMM_PROJ, vp::EPI_BIAS_RESID, c->hid, b.w_fc2, b.b_fc2, c->x, c->x, M, D, 4 * D, D))) {
-                return rc;   // last block: last_norm below is a standalone pass (deconv taps gather different rows)
-            }
+            if ((rc = gemm(c, VP_PROF_GEMM_FC1, vp::EPI_BIAS_GELU, xh, b.w_fc1, b.b_fc1, c->hid, nullptr, M, 4 * D, D, 4 * D, 0, 0, 0, &c1))) return rc;
+            if ((rc = gemm(c, VP_PROF_GEMM_PROJ, vp::EPI_BIAS_RESID_LN, c->hid, b.w_fc2, b.b_fc2, c->x, c->x, M, D, 4 * D, D, 0, 0, 0, &prod))) return rc;
+            if (l + 1 < c->L && (rc = finalize())) return rc;   // last block: last_norm below is a standalone pass
         }
     } else {
     if ((rc = gemm(c, VP_PROF_GEMM_PATCH, vp::EPI_POS, c->hid, c->w_patch, c->b_zero, c->x, c->pos, M, D, 768, D))) return rc;
@@ -387,7 +386,7 @@ int forward_chunk(vp_ctx* c, const void* d_crops, int fmt, int n, bool want_toke
     }
     }
     LAUNCH(c, VP_PROF_LAYERNORM, 0.0, 6.0 * M * D,
-           vp::layernorm_launch(c->dtype, c->x, c->lnf_g, c->lnf_b, c->y, want_tokens ? c->tok : nullptr, M, D, c->stream));
+           vp::layernorm_launch(c->dtype, c->x, c->lnf_g, c->lnf_b, c->y, want_tokens ? c->tok : nullptr, M, D, c->stream, plane));
     // head: tokens [n,16,12,D] (NHWC view of [n*192, D]) -> [n,32,24,256] -> [n,64,48,256] -> heatmaps [n,Kp,64,48]
     if ((rc = gemm(c, VP_PROF_GEMM_DECONV, vp::EPI_DECONV, c->y, c->w_d1, c->b_d1, c->d1, nullptr, n * 192, 256, 4 * D, 256, 16, 12, D))) return rc;
     if ((rc = gemm(c, VP_PROF_GEMM_DECONV, vp::EPI_DECONV, c->d1, c->w_d2, c->b_d2, c->d2, nullptr, n * 768, 256, 1024, 256, 32, 24, 256))) return rc;
@@ -455,7 +454,6 @@ int vp_create(vp_handle* out, const vp_config* cfg) {
     if ((rc = dalloc(c, &c->y, M * D))) return bail(rc);
     if (const char* f = getenv("VP_FUSE_LN")) c->fuse_ln = atoi(f) != 0;
     if (c->fuse_ln) {
-        if ((rc = dalloc(c, &c->x16, M * D))) return bail(rc);
         if ((rc = dalloc(c, &c->ln_part, M * (size_t)(D / 64) * 2))) return bail(rc);
         if ((rc = dalloc(c, &c->rowstat, M * 2))) return bail(rc);
     }
