@@ -61,14 +61,15 @@ def load_library():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    lib_path = os.environ.get('VP_HIP_LIB', LIB_PATH)   # kernel development only: A/B two builds on the same box
+    if not os.path.exists(lib_path):
         raise HipExtensionMissing(
-            f'{LIB_PATH} not found. Build it with `python -m easy_vitpose_amd.build` '
+            f'{lib_path} not found. Build it with `python -m easy_vitpose_amd.build` '
             '(needs hipcc). There is no CPU fallback for the ViTPose path.')
     try:
-        lib = C.CDLL(LIB_PATH)
+        lib = C.CDLL(lib_path)
     except OSError as e:  # e.g. libamdhip64 missing
-        raise HipExtensionMissing(f'cannot load {LIB_PATH}: {e}') from e
+        raise HipExtensionMissing(f'cannot load {lib_path}: {e}') from e
     H = C.c_void_p
     lib.vp_abi_version.restype = C.c_int
     lib.vp_create.argtypes = [C.POINTER(H), C.POINTER(vp_config)]

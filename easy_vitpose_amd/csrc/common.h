@@ -41,6 +41,15 @@ template <class T> __device__ __forceinline__ uint32_t pack2(float lo, float hi)
     return (uint32_t)to_bits<T>(lo) | ((uint32_t)to_bits<T>(hi) << 16);
 }
 
+// as pack2 for values known to be far inside the 16-bit range (no saturation clamp)
+template <class T> __device__ __forceinline__ uint32_t pack2_nosat(float lo, float hi);
+template <> __device__ __forceinline__ uint32_t pack2_nosat<F16>(float lo, float hi) {
+    typedef __attribute__((ext_vector_type(2))) _Float16 h2;
+    const h2 v = {(_Float16)lo, (_Float16)hi};
+    return __builtin_bit_cast(uint32_t, v);
+}
+template <> __device__ __forceinline__ uint32_t pack2_nosat<BF16>(float lo, float hi) { return pack2<BF16>(lo, hi); }
+
 // ---- MFMA: D(16x16) += A(16x32) * B(32x16) ----
 // fragment layout (gfx950): A lane l holds A[row = l&15][k = (l>>4)*8 .. +7],
 //                           B lane l holds B[k = (l>>4)*8 .. +7][col = l&15],

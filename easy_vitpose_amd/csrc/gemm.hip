@@ -529,14 +529,10 @@ __global__ __launch_bounds__(C::NT, 2) void gemm_kernel(GemmArgs g) {
                     }
                     u32x4 oh, ol;
 #pragma unroll
-                    for (int e = 0; e < 8; e += 2) {
+                    for (int e = 0; e < 8; e += 2) {   // lo = round16(x - hi) is tiny: no saturation needed
                         const uint16_t h0 = to_bits<T>(v[e]), h1 = to_bits<T>(v[e + 1]);
-                        const uint16_t l0 = to_bits<T>(v[e] - from_bits<T>(h0)), l1 = to_bits<T>(v[e + 1] - from_bits<T>(h1));
                         oh[e >> 1] = (uint32_t)h0 | ((uint32_t)h1 << 16);
-                        ol[e >> 1] = (uint32_t)l0 | ((uint32_t)l1 << 16);
-                        // the statistics are those of the value the planes actually hold
-                        v[e] = from_bits<T>(h0) + from_bits<T>(l0);
-                        v[e + 1] = from_bits<T>(h1) + from_bits<T>(l1);
+                        ol[e >> 1] = pack2_nosat<T>(v[e] - from_bits<T>(h0), v[e + 1] - from_bits<T>(h1));
                     }
                     if (!(g.ablate & 8)) {
                         *(u32x4*)(out_hi + orow_q[q] + n0 + ch * 8) = oh;
