@@ -1,0 +1,86 @@
+#!/usr/bin/env python3
+"""Analysis script (not a test): where does the fp16 path's heatmap error come from?
+
+Emulates on the CPU the device pipeline's rounding points (16-bit operands / stored activations, fp32
+accumulation and residual stream) one group at a time and reports each group's share of the heatmap error
+variance against the fp32 oracle.  Used to decide which stages deserve more precision.
+
+    python tests/precision_budget.py [--variant s] [--crops 4] [--dtype fp16]
+"""
+import argparse
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from easy_vitpose_amd.configs import model_shape
+from easy_vitpose_amd.synth import synthetic_crops, synthetic_state_dict
+from oracle import vitpose_cpu as O
+
+ap = argparse.ArgumentParser()
+ap.add_argument('--variant', default='s')
+ap.add_argument('--crops', type=int, default=4)
+ap.add_argument('--dtype', default='fp16')
+args = ap.parse_args()
+DT = torch.float16 if args.dtype == 'fp16' else torch.bfloat16
+
+GROUPS = ['patch_in', 'patch_w', 'ln_out', 'qkv_w', 'qkv_out', 'attn_p', 'attn_out', 'proj_w', 'fc1_w', 'hid', 'fc2_w',
+          'lastnorm_out', 'd1_w', 'd1_out', 'd2_w', 'd2_out', 'final_w']
+
+
+def fwd(sd, x, depth, heads, on):
+    def r(t, g):
+        return t.to(DT).float() if g in on else t
+    w = sd['backbone.patch_embed.proj.weight']
+    x = F.conv2d(r(x, 'patch_in'), r(w, 'patch_w'), sd['backbone.patch_embed.proj.bias'], stride=16, padding=2)
+    B, D, Hp, Wp = x.shape
+    x = x.view(B, D, Hp * Wp).transpose(1, 2)
+    pos = sd['backbone.pos_embed']
+    x = x + pos[:, 1:] + pos[:, :1]
+    hd = D // heads
+    for i in range(depth):
+        p = f'backbone.blocks.{i}.'
+        y = r(F.layer_norm(x, (D,), sd[p + 'norm1.weight'], sd[p + 'norm1.bias'], eps=1e-6), 'ln_out')
+        qkv = r(F.linear(y, r(sd[p + 'attn.qkv.weight'], 'qkv_w'), sd[p + 'attn.qkv.bias']), 'qkv_out')
+        qkv = qkv.reshape(B, Hp * Wp, 3, heads, hd).permute(2, 0, 3, 1, 4)
+        q, k, v = qkv[0], qkv[1], qkv[2]
+        s = (q @ k.transpose(-2, -1)) * hd ** -0.5
+        e = torch.exp(s - s.max(-1, keepdim=True).values)
+        y = (r(e, 'attn_p') @ v) / e.sum(-1, keepdim=True)          # device: P un-normalised in 16 bit, 1/l in fp32
+        y = r(y.transpose(1, 2).reshape(B, Hp * Wp, D), 'attn_out')
+        x = x + F.linear(y, r(sd[p + 'attn.proj.weight'], 'proj_w'), sd[p + 'attn.proj.bias'])
+        y = r(F.layer_norm(x, (D,), sd[p + 'norm2.weight'], sd[p + 'norm2.bias'], eps=1e-6), 'ln_out')
+        y = r(F.gelu(F.linear(y, r(sd[p + 'mlp.fc1.weight'], 'fc1_w'), sd[p + 'mlp.fc1.bias'])), 'hid')
+        x = x + F.linear(y, r(sd[p + 'mlp.fc2.weight'], 'fc2_w'), sd[p + 'mlp.fc2.bias'])
+    x = r(F.layer_norm(x, (D,), sd['backbone.last_norm.weight'], sd['backbone.last_norm.bias'], eps=1e-6), 'lastnorm_out')
+    x = x.permute(0, 2, 1).reshape(B, D, 16, 12)
+    h = 'keypoint_head.deconv_layers.'
+    for idx, tag in ((0, 'd1'), (3, 'd2')):
+        # the device folds BatchNorm (eval) into the deconv weights before rounding them
+        sc = sd[f'{h}{idx + 1}.weight'] / torch.sqrt(sd[f'{h}{idx + 1}.running_var'] + 1e-5)
+        wf = r(sd[f'{h}{idx}.weight'] * sc.view(1, -1, 1, 1), tag + '_w')
+        bf = sd[f'{h}{idx + 1}.bias'] - sd[f'{h}{idx + 1}.running_mean'] * sc
+        x = r(F.relu(F.conv_transpose2d(x, wf, bf, stride=2, padding=1)), tag + '_out')
+    return F.conv2d(x, r(sd['keypoint_head.final_layer.weight'], 'final_w'), sd['keypoint_head.final_layer.bias'])
+
+
+with torch.no_grad():
+    shp = model_shape(args.variant, 'coco')
+    sd = O.to_torch_state_dict(synthetic_state_dict(shp, 0))
+    crops = synthetic_crops(args.crops, 8, 'noise')
+    x = torch.from_numpy(np.concatenate([O.pre_img(c)[0] for c in crops]))
+    ref = fwd(sd, x, shp.depth, shp.num_heads, set())
+    full = fwd(sd, x, shp.depth, shp.num_heads, set(GROUPS)) - ref
+    tot = float((full ** 2).mean())
+    print(f'variant {args.variant} {args.dtype}: heatmap std {float(ref.std()):.3f}; all roundings: rms {tot ** 0.5:.3e} max {float(full.abs().max()):.3e}')
+    rows = []
+    for g in GROUPS:
+        e = fwd(sd, x, shp.depth, shp.num_heads, {g}) - ref
+        rows.append((float((e ** 2).mean()), g))
+    s = sum(v for v, _ in rows)
+    for v, g in sorted(rows, reverse=True):
+        print(f'  {g:14s} rms {v ** 0.5:.3e}  {100 * v / s:5.1f} % of the summed variance')
+    print(f'  sum of single-group variances / all-on variance = {s / tot:.2f}')
