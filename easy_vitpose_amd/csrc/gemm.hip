@@ -198,7 +198,7 @@ __global__ __launch_bounds__(C::NT, 2) void gemm_kernel(GemmArgs g) {
         if (m > g.M - 1) m = g.M - 1;
         const int sl = swz<C::BK>(r, pslot) * 8;
         if (AMODE == A_DENSE) {
-            asrc[p] = g.A + (size_t)m * K + sl;
+            asrc[p] = g.a_blocked ? g.A + ((size_t)(m >> 6) * (K >> 6) << 12) + ((m & 63) << 6) + sl : g.A + (size_t)m * K + sl;
         } else {
             const int t = m / g.Win;
             ai[p] = t % g.Hin;
@@ -212,8 +212,9 @@ __global__ __launch_bounds__(C::NT, 2) void gemm_kernel(GemmArgs g) {
 #pragma unroll
         for (int p = 0; p < C::WP; ++p) glds16(wsrc[p] + k0, base + p * (C::NWAVES * 1024));
         if (AMODE == A_DENSE) {
+            const int ka = g.a_blocked ? ((k0 >> 6) << 12) + (k0 & 63) : k0;   // 64x64-blocked A: next k block = +4096 elements
 #pragma unroll
-            for (int p = 0; p < C::AP; ++p) glds16(asrc[p] + k0, base + C::W_BYTES + p * (C::NWAVES * 1024));
+            for (int p = 0; p < C::AP; ++p) glds16(asrc[p] + ka, base + C::W_BYTES + p * (C::NWAVES * 1024));
         } else {
             const int tap = k0 / g.Cin, c0 = k0 - tap * g.Cin;
             const int ti = tap >> 1, tj = tap & 1;
@@ -658,6 +659,11 @@ __global__ __launch_bounds__(C::NT, 2) void gemm_kernel(GemmArgs g) {
                     if (ES == 2) {
                         const u32x4 v = *(const u32x4*)src;
                         uint16_t* dst = (uint16_t*)g.out + orow_q[q] + n;
+                        if (EPI != EPI_DECONV && g.out_blocked) {   // [M/64][N/64][64][64] blocks (the next GEMM's A tiles)
+                            const int wmr = lr / (JP * 16), rr = lr - wmr * (JP * 16);
+                            const int m = m0 + wmr * C::WM + p * JP * 16 + rr;
+                            dst = (uint16_t*)g.out + (((size_t)(m >> 6) * (g.ldo >> 6) + (n >> 6)) << 12) + ((m & 63) << 6) + (n & 63);
+                        }
                         if (n + 8 <= g.N) *(u32x4*)dst = v;
                         else *(u32x2*)dst = u32x2{v[0], v[1]};   // N % 8 == 4 tail (N % 4 == 0 is required)
                     } else {
@@ -801,6 +807,8 @@ hipError_t gemm_launch(int dtype, int epi, const GemmArgs& a, hipStream_t s) {
     if (a.K % 64 != 0 || a.M <= 0 || a.N <= 0) return hipErrorInvalidValue;
     if (epi == EPI_DECONV && (a.Cin % 64 != 0 || a.K != 4 * a.Cin)) return hipErrorInvalidValue;
     if (epi != EPI_HEATMAP && (a.N % 4 != 0 || a.ldo % 4 != 0)) return hipErrorInvalidValue;  // 8/16-byte epilogue stores
+    if (a.a_blocked && (epi == EPI_DECONV || (a.M & 63))) return hipErrorInvalidValue;
+    if (a.out_blocked && ((epi != EPI_BIAS && epi != EPI_BIAS_GELU) || (a.M & 63) || (a.N & 63) || a.ldo != a.N)) return hipErrorInvalidValue;
     if ((epi == EPI_BIAS_RESID_LN || epi == EPI_POS_LN) && (a.N % 64 != 0 || !a.plane || !a.stats_out)) return hipErrorInvalidValue;
     return dtype == DT_F16 ? dispatch<F16>(epi, a, s) : dispatch<BF16>(epi, a, s);
 }

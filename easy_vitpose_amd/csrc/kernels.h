@@ -47,6 +47,10 @@ struct GemmArgs {
     // rowstat[m] = (mean, rstd), ln_s[n] = sum_k W'[n][k], bias[n] = sum_k beta_k W[n][k] + b[n]
     const float* rowstat;
     const float* ln_s;
+    // 64x64-blocked activation layout [M/64][K/64][64][64]: every operand tile of the consuming GEMM is a run of
+    // contiguous 8 KiB blocks (sequential DRAM bursts instead of 128-byte pieces at a row stride).  out_blocked: this
+    // GEMM writes its 16-bit output that way (EPI_BIAS / EPI_BIAS_GELU, ldo == N); a_blocked: A is read that way.
+    int a_blocked, out_blocked;
     int ablate;           // profiling only (tools/gemm_ablate.py): 1 = no operand loads after the prologue, 2 = every tile loads the A rows of m-tile 0 (A L2-resident), 8 = no epilogue stores
 };
 hipError_t gemm_launch(int dtype, int epi, const GemmArgs& a, hipStream_t s);
