@@ -82,7 +82,7 @@ def pmc_traffic(args):
         return None
     try:
         for k, d in json.load(open(path)).items():
-            if k.startswith('gemm_kernel<F16, 2, 0') and 'hbm_bytes_per_dispatch' in d:
+            if k.startswith('gemm_kernel<F16, 6, 0') and 'hbm_bytes_per_dispatch' in d:
                 return d['hbm_bytes_per_dispatch']
     except Exception:
         pass
@@ -151,7 +151,8 @@ def main():
     for _ in range(args.warmup):
         step()
     # dominant kernel symbol by total time (rocprofv3 --stats, profiles/r1_tuned_path_rocprofv3.txt): the GEMM with
-    # the fp32 bias+residual epilogue, launched 24x per step (attn.proj K=D and mlp.fc2 K=4D, both N=D)
+    # the bias + residual + LayerNorm-statistics epilogue (gemm_kernel<F16, 6, 0, ...> = EPI_BIAS_RESID_LN), launched
+    # 24x per step (attn.proj K=D and mlp.fc2 K=4D, both N=D)
     dom = 'gemm_proj_fc2'
     eng.set_profiling([dom])
     eng.reset_profile()
@@ -198,7 +199,7 @@ def main():
                        'gflop_per_person': round(shp.gflop_per_person(), 3)},
             'model_tflops': round(persons_s * shp.gflop_per_person() / 1e3, 1),
             'model_frac_of_mfma_peak': round(persons_s * shp.gflop_per_person() * 1e9 / PEAK_MFMA_16BIT, 4),
-            'roofline': {'bound': 'mfma', 'kernel': 'gemm_kernel<F16, EPI_BIAS_RESID, A_DENSE, TileCfg<192,128,64,96,64,2,1,0>> (attn.proj + mlp.fc2: +bias +fp32 residual; flops = average of the two shapes)',
+            'roofline': {'bound': 'mfma', 'kernel': 'gemm_kernel<F16, EPI_BIAS_RESID_LN, A_DENSE, TileCfg<192,128,64,96,64,2,1,0>> (attn.proj + mlp.fc2: +bias +residual planes +LayerNorm row statistics; flops = average of the two shapes)',
                          'achieved': round(ach / 1e12, 2), 'peak': PEAK_MFMA_16BIT / 1e12, 'unit': 'TFLOP/s',
                          'frac': round(ach / PEAK_MFMA_16BIT, 4), 'traffic': pmc_traffic(args),
                          'launches': d['launches'], 'avg_launch_ms': round(d['ms'] / max(d['launches'], 1), 5),

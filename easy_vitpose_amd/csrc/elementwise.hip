@@ -146,19 +146,24 @@ hipError_t layernorm_launch(int dtype, const float* x, const float* gamma, const
 }
 
 
-// Fused-LayerNorm helper: the residual GEMMs leave per-(row, n-tile) partial sums; fold them in a FIXED
-// order (deterministic, unlike atomics) into (mean, rstd) per token row.
+// Fused-LayerNorm helper: the residual GEMMs leave, per token row and 64-column granule, (sum, M2 about the
+// granule mean).  Fold them in a FIXED order (deterministic, unlike atomics) into (mean, rstd) per row with the
+// pairwise-merge identity  M2 = sum_g [M2_g + 64 (mean_g - mean)^2]  -- no E[x^2] - mean^2 cancellation.
 __global__ __launch_bounds__(256) void ln_finalize_kernel(const float* __restrict__ partials, float* __restrict__ rowstat,
                                                           int M, int tiles, float inv_d) {
     const int m = blockIdx.x * 256 + threadIdx.x;
     if (m >= M) return;
     const float* p = partials + (size_t)m * tiles * 2;
-    float s1 = 0.f, s2 = 0.f;
-    for (int t = 0; t < tiles; ++t) { s1 += p[2 * t]; s2 += p[2 * t + 1]; }
+    float s1 = 0.f;
+    for (int t = 0; t < tiles; ++t) s1 += p[2 * t];
     const float mean = s1 * inv_d;
-    const float var = fmaxf(s2 * inv_d - mean * mean, 0.f);
+    float m2 = 0.f;
+    for (int t = 0; t < tiles; ++t) {
+        const float d = p[2 * t] * (1.0f / 64.0f) - mean;
+        m2 += p[2 * t + 1] + 64.0f * d * d;
+    }
     rowstat[2 * (size_t)m] = mean;
-    rowstat[2 * (size_t)m + 1] = rsqrtf(var + 1e-6f);
+    rowstat[2 * (size_t)m + 1] = rsqrtf(m2 * inv_d + 1e-6f);
 }
 
 hipError_t ln_finalize_launch(const float* partials, float* rowstat, int M, int tiles, int D, hipStream_t s) {

@@ -453,7 +453,7 @@ __global__ __launch_bounds__(C::NT, 2) void gemm_kernel(GemmArgs g) {
         // fp32 (>= 22 significant bits), but the hi plane IS the un-normalised 16-bit operand the next qkv / fc1
         // GEMM reads, so the fusion needs no extra copy.  Rows leave the LDS staging as 8-element chunks: two
         // 16-byte plane loads (residual) and two 16-byte plane stores per lane -- the same instruction count as
-        // the fp32 epilogue.  Partial row statistics (sum, sum of squares) are taken per 64-column granule = 8
+        // the fp32 epilogue.  Partial row statistics (sum, centred sum of squares) are taken per 64-column granule = 8
         // aligned lanes (DPP adds, fixed order: independent of the tile shape, hence of the batch size), parked in
         // LDS and written once per tile.
         constexpr int ROWBYTES = C::BN * 4 + 16;
@@ -540,10 +540,17 @@ __global__ __launch_bounds__(C::NT, 2) void gemm_kernel(GemmArgs g) {
                         *(u32x4*)(out_lo + orow_q[q] + n0 + ch * 8) = ol;
                     }
                 }
+                // granule statistics as (sum, M2 about the granule's own mean): merged exactly by ln_finalize (Chan et
+                // al.), so the fused path has the two-pass LayerNorm's robustness to rows with a large common offset
                 float s1 = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
-                float s2 = ((v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3])) +
-                           ((v[4] * v[4] + v[5] * v[5]) + (v[6] * v[6] + v[7] * v[7]));
                 s1 = row8_sum(s1);
+                const float mg = s1 * (1.0f / 64.0f);
+                float s2 = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float d = v[e] - mg;
+                    s2 = fmaf(d, d, s2);
+                }
                 s2 = row8_sum(s2);
                 if ((ch & 7) == 0) {
                     const int wmr = lr / (JP * 16), rr = lr - wmr * (JP * 16);
@@ -690,6 +697,20 @@ __global__ __launch_bounds__(C::NT, 2) void gemm_kernel(GemmArgs g) {
             } else {
                 orow = (size_t)m * g.ldo;
             }
+            if constexpr (EPI == EPI_HEATMAP) {
+                // weight rows come as [16 hi][16 lo] groups (vitpose_api.hip upload_final): fragments 2u and 2u + 1
+                // are the hi and lo products of output columns (n0 + wn WN) / 2 + 16 u + 4 fg .. + 3
+#pragma unroll
+                for (int u = 0; u < C::TI / 2; ++u) {
+                    const int nb = (n0 + wn * C::WN) / 2 + u * 16 + fg * 4;
+                    if (nb >= g.Kp) continue;
+                    const f32x4 v = acc[2 * u][j] + acc[2 * u + 1][j];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (nb + r < g.Kp) ((float*)g.out)[orow + (size_t)(nb + r) * 3072] = v[r] + g.bias[nb + r];
+                }
+                continue;
+            }
 #pragma unroll
             for (int i = 0; i < C::TI; ++i) {
                 const int nb = n0 + wn * C::WN + i * 16 + fg * 4;
@@ -711,12 +732,8 @@ __global__ __launch_bounds__(C::NT, 2) void gemm_kernel(GemmArgs g) {
                     *(u32x2*)((uint16_t*)g.out + orow + nb) = o;
                 } else if (EPI == EPI_BIAS_RESID) {
                     *(f32x4*)((float*)g.out + orow + nb) = v + *(const f32x4*)(g.aux + orow + nb);
-                } else if (EPI == EPI_POS) {
-                    *(f32x4*)((float*)g.out + orow + nb) = v + *(const f32x4*)(g.aux + (size_t)(m % 192) * g.ldo + nb);
                 } else {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (nb + r < g.N) ((float*)g.out)[orow + (size_t)(nb + r) * 3072] = v[r];
+                    *(f32x4*)((float*)g.out + orow + nb) = v + *(const f32x4*)(g.aux + (size_t)(m % 192) * g.ldo + nb);
                 }
             }
         }

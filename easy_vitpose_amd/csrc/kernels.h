@@ -39,7 +39,7 @@ struct GemmArgs {
     // ---- fused LayerNorm ----
     // producer side (EPI_BIAS_RESID_LN / EPI_POS_LN): the residual stream is two 16-bit planes, x = hi + lo,
     // hi = round16(x) at out / aux, lo = round16(x - hi) `plane` elements behind it; besides the rows the partial
-    // row statistics (sum, sum of squares) of every 64-column granule go to stats_out[(m*(N/64) + n/64)*2]
+    // row statistics (sum, M2 about the granule mean) of every 64-column granule go to stats_out[(m*(N/64) + n/64)*2]
     size_t plane;
     float* stats_out;
     // consumer side (EPI_BIAS / EPI_BIAS_GELU): A is the UN-normalised 16-bit residual stream, W has LayerNorm's
@@ -58,7 +58,7 @@ int gemm_tile_bn(int variant);   // BN of a tile configuration (number of n-tile
 // fill a 16-bit buffer with pseudo-random values in [-1, 1) (benchmark operands)
 hipError_t fill_random16(int dtype, uint16_t* p, size_t n, uint32_t seed, hipStream_t s);
 
-// partial row statistics [M][tiles][2] (sum, sumsq) -> rowstat [M][2] (mean, rstd), LayerNorm eps 1e-6
+// partial row statistics [M][tiles][2] (sum, centred M2 per 64-column granule) -> rowstat [M][2] (mean, rstd), LayerNorm eps 1e-6
 hipError_t ln_finalize_launch(const float* partials, float* rowstat, int M, int tiles, int D, hipStream_t s);
 
 // calibration micro-benchmarks (tools/): kind 0/1 = MFMA 16x16x32 / 32x32x16 f16 TFLOP/s, 2 = float4 copy TB/s

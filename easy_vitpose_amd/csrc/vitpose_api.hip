@@ -70,6 +70,7 @@ struct vp_ctx {
     std::vector<Block> blocks;
     float *lnf_g = nullptr, *lnf_b = nullptr;
     uint16_t *w_d1 = nullptr, *w_d2 = nullptr, *w_fin = nullptr;
+    size_t fin_rows = 0;   // physical (hi/lo interleaved) rows of w_fin
     float *b_d1 = nullptr, *b_d2 = nullptr, *b_fin = nullptr, *b_zero = nullptr;
     uint16_t* zero = nullptr;
     // workspaces
@@ -156,6 +157,30 @@ float host_from_bits(uint16_t h, int dtype) {
 }
 
 size_t pad128(size_t n) { return (n + 255) / 256 * 256; }
+
+// final 1x1 conv weights as a hi + lo pair of 16-bit values (W = hi + lo to ~22 bits): 16-row groups interleaved
+// [16 hi rows][16 lo rows] so that the two MFMA accumulator fragments a lane sums in the EPI_HEATMAP epilogue are
+// the hi and lo products of the SAME output columns.  The GEMM is HBM-bound on its A operand, so the doubled MFMA
+// work is free, and the final layer's weight rounding (9 % of the heatmap error variance, tests/precision_budget.py)
+// disappears.  Physical rows: 32 * ceil(Kp / 16).
+int upload_final(vp_ctx* c, uint16_t** dst, const float* src, size_t kp, size_t cols, size_t* rows_phys) {
+    const size_t groups = (kp + 15) / 16, rows = groups * 32, rows_pad = pad128(rows);
+    std::vector<uint16_t> tmp(rows_pad * cols, 0);
+    for (size_t n = 0; n < kp; ++n)
+        for (size_t k = 0; k < cols; ++k) {
+            const float w = src[n * cols + k];
+            const uint16_t hi = host_to_bits(w, c->dtype);
+            const uint16_t lo = host_to_bits(w - host_from_bits(hi, c->dtype), c->dtype);
+            const size_t r = (n / 16) * 32 + (n % 16);
+            tmp[r * cols + k] = hi;
+            tmp[(r + 16) * cols + k] = lo;
+        }
+    *rows_phys = rows;
+    int rc = dalloc(c, dst, rows_pad * cols);
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpy(*dst, tmp.data(), tmp.size() * 2, hipMemcpyHostToDevice));
+    return VP_OK;
+}
 
 // LayerNorm folded into the following nn.Linear (y = LN(x) W^T + b):
 //   W'[n][k] = gamma[k] W[n][k] (rounded to the operand type), s[n] = sum_k W'[n][k] (of the ROUNDED values, so the
@@ -324,12 +349,13 @@ int gemm(vp_ctx* c, int fam, int epi, const uint16_t* A, const uint16_t* W, cons
         if (ln->tiles_out) *ln->tiles_out = N / 64;   // partial statistics are written per 64 columns, whatever the tile
     }
     const double par = (epi == vp::EPI_DECONV) ? 4.0 : 1.0;
-    const double flops = 2.0 * M * (double)N * K * par;
+    const double Nalg = (epi == vp::EPI_HEATMAP) ? (double)c->Kp : (double)N;   // heatmap: N counts the hi + lo weight rows
+    const double flops = 2.0 * M * Nalg * K * par;
     // algorithmic HBM bytes: each operand once, output once (+ residual read)
     const bool resid = epi == vp::EPI_BIAS_RESID || epi == vp::EPI_BIAS_RESID_LN;
     const bool f32out = resid || epi == vp::EPI_POS || epi == vp::EPI_POS_LN || epi == vp::EPI_HEATMAP;
     const double out_b = f32out ? 4.0 : 2.0;
-    double bytes = 2.0 * M * (double)(epi == vp::EPI_DECONV ? Cin : K) + 2.0 * N * (double)K * par + out_b * M * (double)N * par;
+    double bytes = 2.0 * M * (double)(epi == vp::EPI_DECONV ? Cin : K) + 2.0 * N * (double)K * par + out_b * M * Nalg * par;
     if (resid) bytes += 4.0 * M * (double)N;
     if (epi == vp::EPI_BIAS_RESID_LN || epi == vp::EPI_POS_LN) bytes += 8.0 * M * (double)(N / 64);   // partial row statistics
     LAUNCH(c, fam, flops, bytes, vp::gemm_launch(c->dtype, epi, g, c->stream));
@@ -394,7 +420,7 @@ int forward_chunk(vp_ctx* c, const void* d_crops, int fmt, int n, bool want_toke
     // head: tokens [n,16,12,D] (NHWC view of [n*192, D]) -> [n,32,24,256] -> [n,64,48,256] -> heatmaps [n,Kp,64,48]
     if ((rc = gemm(c, VP_PROF_GEMM_DECONV, vp::EPI_DECONV, c->y, c->w_d1, c->b_d1, c->d1, nullptr, n * 192, 256, 4 * D, 256, 16, 12, D))) return rc;
     if ((rc = gemm(c, VP_PROF_GEMM_DECONV, vp::EPI_DECONV, c->d1, c->w_d2, c->b_d2, c->d2, nullptr, n * 768, 256, 1024, 256, 32, 24, 256))) return rc;
-    if ((rc = gemm(c, VP_PROF_GEMM_FINAL, vp::EPI_HEATMAP, c->d2, c->w_fin, c->b_fin, c->hm, nullptr, n * 3072, c->Kp, 256, 0))) return rc;
+    if ((rc = gemm(c, VP_PROF_GEMM_FINAL, vp::EPI_HEATMAP, c->d2, c->w_fin, c->b_fin, c->hm, nullptr, n * 3072, (int)c->fin_rows, 256, 0))) return rc;
     return VP_OK;
 }
 
@@ -527,7 +553,7 @@ int vp_load_weights(vp_handle c, const vp_tensor_desc* tensors, int32_t n_tensor
     if ((rc = pack_deconv(c, lk, 0, D, &c->w_d1, &c->b_d1))) return rc;
     if ((rc = pack_deconv(c, lk, 3, 256, &c->w_d2, &c->b_d2))) return rc;
     if ((rc = lk.get("keypoint_head.final_layer.weight", (int64_t)c->Kp * 256, &p)) ||
-        (rc = upload_mat(c, &c->w_fin, p, c->Kp, 256, pad128(c->Kp)))) return rc;
+        (rc = upload_final(c, &c->w_fin, p, c->Kp, 256, &c->fin_rows))) return rc;
     if ((rc = lk.get("keypoint_head.final_layer.bias", c->Kp, &p)) || (rc = upload_f32(c, &c->b_fin, p, c->Kp, pad128(c->Kp)))) return rc;
     {
         std::vector<float> z(pad128(4 * (size_t)D), 0.f);
