@@ -164,6 +164,7 @@ __global__ __launch_bounds__(C::NT, 2) void gemm_kernel(GemmArgs g) {
     const int tiles_n = (g.N + C::BN - 1) / C::BN;
     const int tiles_m = (g.M + C::BM - 1) / C::BM;
     int bid = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+    if (g.reverse) bid = tiles_m * tiles_n - 1 - bid;   // walk the tiles last-to-first: start with what the producer wrote last
     int tm, tn;
     if (g.group_m > 1) {   // grouped order: GROUP_M m-tiles x all n-tiles, m fastest inside the group
         const int per_group = g.group_m * tiles_n;

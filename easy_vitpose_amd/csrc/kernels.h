@@ -51,6 +51,9 @@ struct GemmArgs {
     // contiguous 8 KiB blocks (sequential DRAM bursts instead of 128-byte pieces at a row stride).  out_blocked: this
     // GEMM writes its 16-bit output that way (EPI_BIAS / EPI_BIAS_GELU, ldo == N); a_blocked: A is read that way.
     int a_blocked, out_blocked;
+    // tile order last-to-first: a consumer of a tensor larger than the 256 MB Infinity Cache then starts with the
+    // rows its producer wrote last (still cached) instead of the ones already evicted
+    int reverse;
     int ablate;           // profiling only (tools/gemm_ablate.py): 1 = no operand loads after the prologue, 2 = every tile loads the A rows of m-tile 0 (A L2-resident), 8 = no epilogue stores
 };
 hipError_t gemm_launch(int dtype, int epi, const GemmArgs& a, hipStream_t s);

@@ -79,6 +79,7 @@ struct vp_ctx {
     float* x = nullptr;
     uint16_t *y = nullptr, *qkv = nullptr, *hid = nullptr, *d1 = nullptr, *d2 = nullptr;
     float *hm = nullptr, *kp = nullptr, *tok = nullptr;
+    bool reverse_fc2 = true;          // fc2 walks its tiles last-to-first (VP_REVERSE_FC2=0 disables)
     bool blocked_hid = true;          // mlp hidden activations in the 64x64-blocked layout (VP_BLOCKED_HID=0: row-major)
     bool fuse_ln = true;              // LayerNorm folded into the GEMMs on both sides of it (VP_FUSE_LN=0: standalone passes)
     float *ln_part = nullptr, *rowstat = nullptr;   // partial row statistics [M][D/64][2], (mean, rstd) [M][2]
@@ -312,7 +313,7 @@ void apply_gemm_tuning(vp_ctx* c) {
     } while (0)
 
 struct LnFuse {
-    bool a_blocked = false, out_blocked = false;   // 64x64-blocked activation layout on the A / output side (kernels.h)
+    bool a_blocked = false, out_blocked = false, reverse = false;   // 64x64-blocked activation layout on the A / output side (kernels.h)
     size_t plane = 0;                 // producer: elements between the hi and lo planes of the residual stream
     float* stats_out = nullptr;       // producer: partial row statistics
     const float* rowstat = nullptr;   // consumer: (mean, rstd) per row
@@ -344,7 +345,7 @@ int gemm(vp_ctx* c, int fam, int epi, const uint16_t* A, const uint16_t* W, cons
         if (t192 < 384) { g.variant = (t128 >= 256) ? 1 : 9; g.group_m = 0; }
     }
     if (ln) {
-        g.a_blocked = ln->a_blocked; g.out_blocked = ln->out_blocked;
+        g.a_blocked = ln->a_blocked; g.out_blocked = ln->out_blocked; g.reverse = ln->reverse;
         g.plane = ln->plane; g.stats_out = ln->stats_out; g.rowstat = ln->rowstat; g.ln_s = ln->ln_s;
         if (ln->tiles_out) *ln->tiles_out = N / 64;   // partial statistics are written per 64 columns, whatever the tile
     }
@@ -395,7 +396,7 @@ int forward_chunk(vp_ctx* c, const void* d_crops, int fmt, int n, bool want_toke
             if ((rc = finalize())) return rc;
             LnFuse c1; c1.rowstat = c->rowstat; c1.ln_s = b.s_fc1; c1.out_blocked = c->blocked_hid;
             if ((rc = gemm(c, VP_PROF_GEMM_FC1, vp::EPI_BIAS_GELU, xh, b.w_fc1, b.b_fc1, c->hid, nullptr, M, 4 * D, D, 4 * D, 0, 0, 0, &c1))) return rc;
-            LnFuse p2 = prod; p2.a_blocked = c->blocked_hid;
+            LnFuse p2 = prod; p2.a_blocked = c->blocked_hid; p2.reverse = c->reverse_fc2;
             if ((rc = gemm(c, VP_PROF_GEMM_PROJ, vp::EPI_BIAS_RESID_LN, c->hid, b.w_fc2, b.b_fc2, c->x, c->x, M, D, 4 * D, D, 0, 0, 0, &p2))) return rc;
             if (l + 1 < c->L && (rc = finalize())) return rc;   // last block: last_norm below is a standalone pass
         }
@@ -484,6 +485,7 @@ int vp_create(vp_handle* out, const vp_config* cfg) {
     if ((rc = dalloc(c, &c->y, M * D))) return bail(rc);
     if (const char* f = getenv("VP_FUSE_LN")) c->fuse_ln = atoi(f) != 0;
     if (const char* f = getenv("VP_BLOCKED_HID")) c->blocked_hid = atoi(f) != 0;
+    if (const char* f = getenv("VP_REVERSE_FC2")) c->reverse_fc2 = atoi(f) != 0;
     if (c->fuse_ln) {
         if ((rc = dalloc(c, &c->ln_part, M * (size_t)(D / 64) * 2))) return bail(rc);
         if ((rc = dalloc(c, &c->rowstat, M * 2))) return bail(rc);
