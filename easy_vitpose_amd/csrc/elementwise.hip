@@ -9,50 +9,64 @@ namespace vp {
 // PatchEmbed = Conv2d(3, D, k=16, s=16, padding=2) (vit.py:222): patch (py,px) covers
 // rows 16py-2 .. 16py+13, cols 16px-2 .. 16px+13 of the 256x192 crop, zero outside.
 // Row m = b*192 + py*12 + px of the patch matrix, column k = c*256 + ky*16 + kx
-// (the flattening of the conv weight [D,3,16,16]).  One thread = one 16-byte chunk
-// (8 consecutive kx) of the output.
+// (the flattening of the conv weight [D,3,16,16]).
+// One block = one patch row (b, py): its input is 3 x 16 whole image rows (read as contiguous
+// 16-byte pieces), its output 12 consecutive rows of the patch matrix (18 KiB contiguous); the
+// transposition in between goes through LDS, so that both HBM sides are fully coalesced (the
+// thread-per-output-chunk version fetched 2.1x the algorithmic bytes: 64-byte pieces of 128-byte lines).
 template <class Ty, int FMT>
 __global__ __launch_bounds__(256) void im2col_kernel(const void* __restrict__ in, uint16_t* __restrict__ out, int B) {
-    const size_t total = (size_t)B * 192 * 96;
-    for (size_t id = (size_t)blockIdx.x * 256 + threadIdx.x; id < total; id += (size_t)gridDim.x * 256) {
-        const int kc = (int)(id % 96);
-        const size_t m = id / 96;
-        const int c = kc >> 5, ky = (kc & 31) >> 1, kx0 = (kc & 1) * 8;
-        const int t = (int)(m % 192), b = (int)(m / 192);
-        const int py = t / 12, px = t % 12;
-        const int y = 16 * py - 2 + ky;
-        const int x0 = 16 * px - 2 + kx0;
-        float v[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int x = x0 + e;
-            float f = 0.f;
-            if ((unsigned)y < 256u && (unsigned)x < 192u) {
-                if (FMT == VP_INPUT_F32_NCHW) {
-                    f = ((const float*)in)[(((size_t)b * 3 + c) * 256 + y) * 192 + x];
-                } else {
-                    // pre_img (easy_ViTPose/inference.py:316-317): float64 x/255, (x-MEAN)/STD, cast to fp32
-                    const double mean = c == 0 ? 0.485 : (c == 1 ? 0.456 : 0.406);
-                    const double stdv = c == 0 ? 0.229 : (c == 1 ? 0.224 : 0.225);
-                    const uint8_t u = ((const uint8_t*)in)[(((size_t)b * 256 + y) * 192 + x) * 3 + c];
-                    f = (float)(((double)u / 255.0 - mean) / stdv);
-                }
-            }
-            v[e] = f;
+    constexpr int XS = 208;                                  // LDS row: x = -2 .. 205 (index x + 2)
+    __shared__ __attribute__((aligned(16))) uint16_t tile[3 * 16 * XS];
+    const int tid = threadIdx.x;
+    const int b = blockIdx.x >> 4, py = blockIdx.x & 15;
+    const int ytop = 16 * py - 2;
+    if (FMT == VP_INPUT_F32_NCHW) {
+        // 3 channels x 16 rows x 48 float4
+        for (int id = tid; id < 3 * 16 * 48; id += 256) {
+            const int x4 = id % 48, ky = (id / 48) & 15, c = id / (48 * 16);
+            const int y = ytop + ky;
+            f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+            if ((unsigned)y < 256u) v = *(const f32x4*)((const float*)in + (((size_t)b * 3 + c) * 256 + y) * 192 + x4 * 4);
+            uint32_t* dst = (uint32_t*)(tile + (c * 16 + ky) * XS + x4 * 4 + 2);
+            dst[0] = pack2<Ty>(v[0], v[1]);
+            dst[1] = pack2<Ty>(v[2], v[3]);
         }
-        u32x4 o;
-        o[0] = pack2<Ty>(v[0], v[1]);
-        o[1] = pack2<Ty>(v[2], v[3]);
-        o[2] = pack2<Ty>(v[4], v[5]);
-        o[3] = pack2<Ty>(v[6], v[7]);
-        *(u32x4*)(out + id * 8) = o;
+    } else {
+        // 16 rows x 576 bytes (192 px x RGB) as 36 16-byte pieces per row
+        for (int id = tid; id < 16 * 36; id += 256) {
+            const int q = id % 36, ky = id / 36;
+            const int y = ytop + ky;
+            u32x4 raw = u32x4{0, 0, 0, 0};
+            const bool inside = (unsigned)y < 256u;
+            if (inside) raw = *(const u32x4*)((const uint8_t*)in + ((size_t)b * 256 + y) * 576 + q * 16);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int off = q * 16 + e, x = off / 3, c = off - x * 3;
+                // pre_img (easy_ViTPose/inference.py:316-317): float64 x/255, (x-MEAN)/STD, cast to fp32
+                const double mean = c == 0 ? 0.485 : (c == 1 ? 0.456 : 0.406);
+                const double stdv = c == 0 ? 0.229 : (c == 1 ? 0.224 : 0.225);
+                const uint8_t u = (uint8_t)(raw[e >> 2] >> ((e & 3) * 8));
+                const float f = inside ? (float)(((double)u / 255.0 - mean) / stdv) : 0.f;
+                tile[(c * 16 + ky) * XS + x + 2] = to_bits<Ty>(f);
+            }
+        }
+    }
+    if (tid < 96) {   // left zero border (x = -2, -1) of every (c, ky) row
+        tile[(tid >> 1) * XS + (tid & 1)] = 0;
+    }
+    __syncthreads();
+    uint16_t* orow = out + ((size_t)b * 192 + py * 12) * 768;
+    for (int id = tid; id < 12 * 96; id += 256) {
+        const int px = id / 96, kc = id - px * 96;
+        const int c = kc >> 5, ky = (kc & 31) >> 1, kx0 = (kc & 1) * 8;
+        *(u32x4*)(orow + (size_t)id * 8) = *(const u32x4*)(tile + (c * 16 + ky) * XS + 16 * px + kx0);
     }
 }
 
 hipError_t im2col_launch(int dtype, const void* crops, int fmt, uint16_t* out, int B, hipStream_t s) {
-    const size_t total = (size_t)B * 192 * 96;
-    int grid = (int)((total + 255) / 256);
-    if (grid > 8192) grid = 8192;
+    if (B <= 0) return hipSuccess;
+    const int grid = B * 16;   // one block per patch row
 #define VP_I2C(TY, F) hipLaunchKernelGGL((im2col_kernel<TY, F>), dim3(grid), dim3(256), 0, s, crops, out, B)
     if (fmt == VP_INPUT_F32_NCHW) {
         if (dtype == DT_F16) VP_I2C(F16, VP_INPUT_F32_NCHW); else VP_I2C(BF16, VP_INPUT_F32_NCHW);
