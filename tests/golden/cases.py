@@ -55,3 +55,26 @@ def org_sizes(n: int, seed: int) -> np.ndarray:
     wh = np.stack([rng.integers(31, 900, size=n), rng.integers(41, 1200, size=n)], axis=1).astype(np.int32)
     wh[0] = (192, 256)
     return wh
+
+
+def pad_shapes():
+    """(h, w) of the crops fed to the reference's pad_image (taller, wider and exactly 3:4)."""
+    return [(256, 192), (300, 100), (100, 300), (257, 193), (1, 1), (64, 47), (63, 48), (480, 640), (333, 250), (10, 7)]
+
+
+def frame_case():
+    """Synthetic 480x640 frame + detector output [n, 5] (x1, y1, x2, y2, conf) for the caller-level golden: a box
+    whose padded crop is exactly 192x256, a wide one, a tall one touching the frame border, and one below the
+    detector threshold (dropped by the caller)."""
+    import numpy as np
+    rng = np.random.default_rng(5)
+    frame = rng.integers(0, 256, size=(480, 640, 3), dtype=np.uint8)
+    yy, xx = np.mgrid[0:480, 0:640]
+    for cx, cy, r in [(150, 200, 40), (420, 260, 60), (600, 100, 30)]:
+        blob = 120.0 * np.exp(-((xx - cx) ** 2 + (yy - cy) ** 2) / (2.0 * r * r))
+        frame = np.clip(frame.astype(np.float64) * 0.5 + blob[..., None], 0, 255).astype(np.uint8)
+    boxes = np.array([[60.2, 110.4, 231.6, 345.7, 0.91],
+                      [300.0, 180.0, 560.0, 330.0, 0.80],
+                      [575.5, 20.0, 639.0, 300.0, 0.55],
+                      [10.0, 10.0, 50.0, 50.0, 0.20]], dtype=np.float64)
+    return frame, boxes

@@ -12,7 +12,11 @@ cv2 functions are on the path and get a real implementation in the stub:
 * ``cv2.GaussianBlur`` -> scipy.ndimage.correlate1d(mode='mirror') on both axes with
   OpenCV's float32 ``getGaussianKernel`` weights (an implementation independent of
   ``oracle/vitpose_cpu.gaussian_blur``; PARITY UNPINNED vs the real OpenCV binary),
-* ``cv2.resize`` -> identity, asserting the crop is already 256x192.
+* ``cv2.resize`` -> identity when the crop is already 256x192; for the caller-level golden
+  (``frame_inference.npz``, crops of arbitrary size) the repo's own restatement of OpenCV's 8-bit
+  INTER_LINEAR (``easy_vitpose_amd.cropprep.resize_linear_u8``) -- the resize boundary stays
+  PARITY UNPINNED, the golden pins everything around it (box padding/clipping, ``pad_image``,
+  the per-box loop, the offset arithmetic, the key -> id mapping).
 
 Nothing from the reference is copied: the fixtures hold only seeds/shapes and the
 reference's numerical OUTPUTS.  While generating, the script also checks the
@@ -79,8 +83,11 @@ def _install_stubs():
         return out
 
     def resize(img, dsize, interpolation=None):
-        assert (img.shape[1], img.shape[0]) == tuple(dsize), 'cv2.resize shim is identity only'
-        return img
+        if (img.shape[1], img.shape[0]) == tuple(dsize):
+            return img
+        from easy_vitpose_amd.cropprep import resize_linear_u8
+        assert img.dtype == np.uint8
+        return resize_linear_u8(np.ascontiguousarray(img), list(dsize))
 
     cv2.GaussianBlur = GaussianBlur
     cv2.resize = resize
@@ -119,6 +126,51 @@ def main():
 
     VitInference, ViTPose, dyn_model_import = import_reference()
     torch.manual_seed(0)
+
+    # ---------------------------------------------------------------- caller goldens
+    # (first: the reference's config modules share one dict, a 'coco' model built after 'wholebody' keeps K = 133)
+    # (1) the reference's pad_image on seeded crops of assorted shapes
+    from easy_ViTPose.vit_utils.inference import pad_image as ref_pad_image
+    from cases import frame_case, pad_shapes
+    rows = []
+    for i, (h, w) in enumerate(pad_shapes()):
+        img = np.random.default_rng(100 + i).integers(0, 256, size=(h, w, 3), dtype=np.uint8)
+        out, (left, top) = ref_pad_image(img, 3 / 4)
+        rows.append([h, w, out.shape[0], out.shape[1], left, top, int(out.astype(np.int64).sum()),
+                     int((out[top:top + h, left:left + w] != img).sum())])
+    np.savez_compressed(os.path.join(HERE, 'pad_image.npz'), rows=np.asarray(rows, dtype=np.int64))
+
+    # (2) the reference's VitInference.inference(img) end to end on a synthetic frame: a fake detector object with
+    #     the ultralytics result interface feeds the reference's own box loop (inference.py:221-281)
+    frame, boxes = frame_case()
+
+    class _Arr:
+        def __init__(self, a): self.a = a
+        def cpu(self): return self
+        def numpy(self): return self.a
+
+    class _Res:
+        def __init__(self, a): self.boxes = types.SimpleNamespace(data=_Arr(a))
+
+    shp = model_shape('s', 'coco')
+    sd = synthetic_state_dict(shp, seed=0)
+    V = build_ref(VitInference, ViTPose, dyn_model_import, 'coco', 's', sd)
+    V.yolo = lambda img, **kw: [_Res(boxes.copy())]
+    V.tracker = None
+    V.frame_counter = 0
+    V.yolo_step = 1
+    V.yolo_size = 320
+    V.yolo_classes = [0]
+    V.save_state = True
+    V._inference = V._inference_torch
+    with torch.no_grad():
+        res = V.inference(frame.copy())
+    ids = sorted(res.keys())
+    kp = np.stack([res[i] for i in ids]).astype(np.float32)
+    tb, tids, tscores = V._tracker_res
+    print(f'frame golden: {len(ids)} persons, padded boxes {np.asarray(tb).tolist()}')
+    np.savez_compressed(os.path.join(HERE, 'frame_inference.npz'), ids=np.asarray(ids), keypoints=kp,
+                        padded_boxes=np.asarray(tb, dtype=np.int64), scores=np.asarray(tscores, dtype=np.float64))
 
     # ---------------------------------------------------------------- decode goldens
     for tag, (n, k, seed) in {'decode_k17': (8, 17, 11), 'decode_k133': (2, 133, 12)}.items():

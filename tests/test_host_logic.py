@@ -88,6 +88,36 @@ def test_crop_params_follow_reference_geometry():
         assert np.array_equal(resize_linear_u8(padded, (192, 256)), crops[i])
 
 
+def test_pad_image_matches_reference_golden():
+    """Outputs of the reference's own pad_image (vit_utils/inference.py:41-70) on seeded crops, made by
+    tests/golden/make_golden.py: padded shape, pads, pixel sum, and the source kept intact inside the padding."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, 'tests', 'golden'))
+    from cases import pad_shapes
+    rows = np.load(os.path.join(ROOT, 'tests', 'golden', 'pad_image.npz'))['rows']
+    assert len(rows) == len(pad_shapes())
+    for i, ((h, w), row) in enumerate(zip(pad_shapes(), rows)):
+        img = np.random.default_rng(100 + i).integers(0, 256, size=(h, w, 3), dtype=np.uint8)
+        out, (left, top) = pad_image(img, 3 / 4)
+        assert [h, w, out.shape[0], out.shape[1], left, top, int(out.astype(np.int64).sum())] == row[:7].tolist()
+        assert int((out[top:top + h, left:left + w] != img).sum()) == row[7] == 0
+
+
+def test_crop_geometry_matches_reference_frame_golden():
+    """The reference's VitInference.inference box loop (inference.py:252-262) run by make_golden.py on the frame of
+    tests/golden/cases.frame_case: threshold 0.35, round, +10 px, clip -> the padded boxes it saved in _tracker_res."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, 'tests', 'golden'))
+    from cases import frame_case
+    g = np.load(os.path.join(ROOT, 'tests', 'golden', 'frame_inference.npz'))
+    frame, boxes = frame_case()
+    det = boxes[boxes[:, 4] > 0.35]
+    p = crop_params(det[:, :4].round().astype(int), frame.shape[:2], 10)
+    mine = np.stack([p[:, 0], p[:, 1], p[:, 0] + p[:, 2], p[:, 1] + p[:, 3]], 1)
+    assert np.array_equal(mine, g['padded_boxes'])
+    assert g['scores'].tolist() == det[:, 4].tolist() and g['ids'].tolist() == [0, 1, 2]
+
+
 def test_shard_bounds_cover_and_balance():
     for n in (0, 1, 7, 8, 64, 65, 257):
         for w in (1, 2, 4, 8):
