@@ -748,7 +748,10 @@ __global__ __launch_bounds__(C::NT, 2) void gemm_kernel(GemmArgs g) {
 // 256x256 halves the L2->LDS operand traffic but runs 1 block / CU (epilogue exposed, tail wave at N = D);
 // Cfg6 is the staggered two-group (anti-phase wave pairs) schedule; Cfg5 the fragment-store A/B reference;
 // Cfg10 = Cfg8 with hand-scheduled inline-asm ds_reads and counted lgkmcnt (bare loop +7 %, end to end +0-2 %:
-// the operand stream, not the intra-wave schedule, is what bounds these GEMMs).
+// the operand stream, not the intra-wave schedule, is what bounds these GEMMs).  Cfg11 = the Cfg8 block tile cut
+// into 8 wave tiles of 48x64: same main-loop rate (LDS reads are at 18 % utilisation, so the smaller wave tile
+// costs nothing), but twice the threads for the VALU-heavy residual epilogue (plane split + LayerNorm statistics):
+// proj+fc2 4.54 -> 4.30 ms per step; no gain for qkv / fc1, slower for the deconvs (96x32 wave tiles: -25 %).
 //                    BM   BN  BK   WM  WN  STAGES PIPE DIRECT      LDS   waves
 using Cfg0 = TileCfg<128, 128, 64, 64, 64, 2, 0, 0>;    //  64 KiB   4   (2 blocks / CU)
 using Cfg1 = TileCfg<128, 128, 64, 64, 64, 2, 1, 0>;    //  same + pipelined fragment reads
@@ -761,7 +764,8 @@ using Cfg7 = TileCfg<192, 256, 64, 96, 64, 2, 1, 0>;    // 112 KiB   8   (1 bloc
 using Cfg8 = TileCfg<192, 128, 64, 96, 64, 2, 1, 0>;    //  80 KiB   4   (2 blocks / CU)  <- default
 using Cfg9 = TileCfg<64, 64, 64, 32, 32, 2, 0, 0>;      //  32 KiB   4   (5 blocks / CU)  small batches: enough tiles to fill 256 CUs
 using Cfg10 = TileCfg<192, 128, 64, 96, 64, 2, 5, 0>;   //  Cfg8 with the hand-scheduled (inline-asm ds_read, counted lgkmcnt) fragment pipeline
-static constexpr int NUM_TILE_CFGS = 11;
+using Cfg11 = TileCfg<192, 128, 64, 48, 64, 2, 1, 0>;  //  80 KiB   8   Cfg8 tile as 8 waves of 48x64 (4 waves / SIMD, 122 VGPRs)  <- default for the residual GEMMs
+static constexpr int NUM_TILE_CFGS = 12;
 
 template <class T, int EPI, int AMODE, class C>
 static hipError_t launch(const GemmArgs& a, hipStream_t s) {
@@ -797,6 +801,7 @@ static hipError_t by_variant(const GemmArgs& a, hipStream_t s) {
         case 8: return launch<T, EPI, AMODE, Cfg8>(a, s);
         case 9: return launch<T, EPI, AMODE, Cfg9>(a, s);
         case 10: return launch<T, EPI, AMODE, Cfg10>(a, s);
+        case 11: return launch<T, EPI, AMODE, Cfg11>(a, s);
     }
     return hipErrorInvalidValue;
 }
@@ -817,7 +822,7 @@ static hipError_t dispatch(int epi, const GemmArgs& a, hipStream_t s) {
 }
 
 int gemm_tile_bn(int variant) {
-    static const int bn[NUM_TILE_CFGS] = {Cfg0::BN, Cfg1::BN, Cfg2::BN, Cfg3::BN, Cfg4::BN, Cfg5::BN, Cfg6::BN, Cfg7::BN, Cfg8::BN, Cfg9::BN, Cfg10::BN};
+    static const int bn[NUM_TILE_CFGS] = {Cfg0::BN, Cfg1::BN, Cfg2::BN, Cfg3::BN, Cfg4::BN, Cfg5::BN, Cfg6::BN, Cfg7::BN, Cfg8::BN, Cfg9::BN, Cfg10::BN, Cfg11::BN};
     return (variant >= 0 && variant < NUM_TILE_CFGS) ? bn[variant] : 0;
 }
 

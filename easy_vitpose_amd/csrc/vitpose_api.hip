@@ -335,7 +335,7 @@ int gemm(vp_ctx* c, int fam, int epi, const uint16_t* A, const uint16_t* W, cons
         // default: the 192(m) x 128(n) tile -- M is always a multiple of 192 tokens (one crop per m-tile), so
         // the tile count divides evenly over 256 CUs x 2 blocks at the BASELINE batch; best or tied for every
         // encoder GEMM in the MI355X sweep (profiles/gemm_tune_r1.txt).  Wide-N GEMMs use the grouped order.
-        g.variant = 8;
+        g.variant = (epi == vp::EPI_BIAS_RESID || epi == vp::EPI_BIAS_RESID_LN) ? 11 : 8;   // residual GEMMs: same tile, 8 waves
         g.group_m = (epi == vp::EPI_BIAS || epi == vp::EPI_BIAS_GELU) ? 8 : 0;
         // small batches (e.g. 8 crops per GPU of a sharded frame): fall back to tiles that still give the
         // 256 CUs at least one block each
