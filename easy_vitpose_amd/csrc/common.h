@@ -20,15 +20,12 @@ template <class T> __device__ __forceinline__ uint16_t to_bits(float v);
 template <> __device__ __forceinline__ uint16_t to_bits<F16>(float v) {
     // saturate instead of overflowing to inf: activations are bounded in practice,
     // but a clamp is cheaper than a NaN three layers later
-    v = fminf(fmaxf(v, -65504.f), 65504.f);
+    v = __builtin_amdgcn_fmed3f(v, -65504.f, 65504.f);
     _Float16 h = (_Float16)v;
     return __builtin_bit_cast(uint16_t, h);
 }
 template <> __device__ __forceinline__ uint16_t to_bits<BF16>(float v) {
-    uint32_t u = __builtin_bit_cast(uint32_t, v);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);  // NaN
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (uint16_t)(u >> 16);
+    return __builtin_bit_cast(uint16_t, (__bf16)v);   // v_cvt_pk_bf16_f32 on gfx950: round to nearest even, NaN kept quiet
 }
 template <class T> __device__ __forceinline__ float from_bits(uint16_t b);
 template <> __device__ __forceinline__ float from_bits<F16>(uint16_t b) {
@@ -39,6 +36,16 @@ template <> __device__ __forceinline__ float from_bits<BF16>(uint16_t b) {
 }
 template <class T> __device__ __forceinline__ uint32_t pack2(float lo, float hi) {
     return (uint32_t)to_bits<T>(lo) | ((uint32_t)to_bits<T>(hi) << 16);
+}
+template <> __device__ __forceinline__ uint32_t pack2<F16>(float lo, float hi) {    // 2 v_med3_f32 (saturate) + one v_cvt_pk_f16_f32
+    typedef __attribute__((ext_vector_type(2))) _Float16 h2;
+    const h2 v = {(_Float16)__builtin_amdgcn_fmed3f(lo, -65504.f, 65504.f), (_Float16)__builtin_amdgcn_fmed3f(hi, -65504.f, 65504.f)};
+    return __builtin_bit_cast(uint32_t, v);
+}
+template <> __device__ __forceinline__ uint32_t pack2<BF16>(float lo, float hi) {   // one v_cvt_pk_bf16_f32
+    typedef __attribute__((ext_vector_type(2))) __bf16 b2;
+    const b2 v = {(__bf16)lo, (__bf16)hi};
+    return __builtin_bit_cast(uint32_t, v);
 }
 
 // as pack2 for values known to be far inside the 16-bit range (no saturation clamp)
