@@ -142,7 +142,8 @@ __global__ __launch_bounds__(256, QT == 3 ? 2 : 3) void attention_kernel(const u
             }
         }
 
-        // ---- softmax over keys (per query column), fp32; P re-packed as PV B-fragments ----
+        // ---- softmax over keys (per query column), fp32; P re-packed as PV B-fragments.  P is in [0, 1] and O a convex
+        //      combination of 16-bit V values: neither can overflow the 16-bit range, so no saturating conversion ----
         u32x4 pf[QT][6];
         float inv_l[QT];
 #pragma unroll
@@ -169,10 +170,10 @@ __global__ __launch_bounds__(256, QT == 3 ? 2 : 3) void attention_kernel(const u
             inv_l[t] = 1.0f / l;
 #pragma unroll
             for (int kb = 0; kb < 6; ++kb) {
-                pf[t][kb][0] = pack2<Ty>(s[t][2 * kb][0], s[t][2 * kb][1]);
-                pf[t][kb][1] = pack2<Ty>(s[t][2 * kb][2], s[t][2 * kb][3]);
-                pf[t][kb][2] = pack2<Ty>(s[t][2 * kb + 1][0], s[t][2 * kb + 1][1]);
-                pf[t][kb][3] = pack2<Ty>(s[t][2 * kb + 1][2], s[t][2 * kb + 1][3]);
+                pf[t][kb][0] = pack2_nosat<Ty>(s[t][2 * kb][0], s[t][2 * kb][1]);
+                pf[t][kb][1] = pack2_nosat<Ty>(s[t][2 * kb][2], s[t][2 * kb][3]);
+                pf[t][kb][2] = pack2_nosat<Ty>(s[t][2 * kb + 1][0], s[t][2 * kb + 1][1]);
+                pf[t][kb][3] = pack2_nosat<Ty>(s[t][2 * kb + 1][2], s[t][2 * kb + 1][3]);
             }
         }
 
@@ -204,15 +205,15 @@ __global__ __launch_bounds__(256, QT == 3 ? 2 : 3) void attention_kernel(const u
                 uint16_t* dst = out + ((size_t)b * T + q) * D + h * HD;
                 if constexpr (C::PAIR) {   // accumulator rows of the pair = d 16 dp + 8 fg + {0..3} and + {4..7}
                     u32x4 w;
-                    w[0] = pack2<Ty>(o[0][t][0] * inv_l[t], o[0][t][1] * inv_l[t]);
-                    w[1] = pack2<Ty>(o[0][t][2] * inv_l[t], o[0][t][3] * inv_l[t]);
-                    w[2] = pack2<Ty>(o[1][t][0] * inv_l[t], o[1][t][1] * inv_l[t]);
-                    w[3] = pack2<Ty>(o[1][t][2] * inv_l[t], o[1][t][3] * inv_l[t]);
+                    w[0] = pack2_nosat<Ty>(o[0][t][0] * inv_l[t], o[0][t][1] * inv_l[t]);
+                    w[1] = pack2_nosat<Ty>(o[0][t][2] * inv_l[t], o[0][t][3] * inv_l[t]);
+                    w[2] = pack2_nosat<Ty>(o[1][t][0] * inv_l[t], o[1][t][1] * inv_l[t]);
+                    w[3] = pack2_nosat<Ty>(o[1][t][2] * inv_l[t], o[1][t][3] * inv_l[t]);
                     *(u32x4*)(dst + dp * 16 + fg * 8) = w;
                 } else {
                     u32x2 w;
-                    w[0] = pack2<Ty>(o[0][t][0] * inv_l[t], o[0][t][1] * inv_l[t]);
-                    w[1] = pack2<Ty>(o[0][t][2] * inv_l[t], o[0][t][3] * inv_l[t]);
+                    w[0] = pack2_nosat<Ty>(o[0][t][0] * inv_l[t], o[0][t][1] * inv_l[t]);
+                    w[1] = pack2_nosat<Ty>(o[0][t][2] * inv_l[t], o[0][t][3] * inv_l[t]);
                     *(u32x2*)(dst + dp * 16 + fg * 4) = w;
                 }
             }
