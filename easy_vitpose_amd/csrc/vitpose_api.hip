@@ -79,7 +79,7 @@ struct vp_ctx {
     float* x = nullptr;
     uint16_t *y = nullptr, *qkv = nullptr, *hid = nullptr, *d1 = nullptr, *d2 = nullptr;
     float *hm = nullptr, *kp = nullptr, *tok = nullptr;
-    bool reverse_fc2 = true;          // fc2 walks its tiles last-to-first (VP_REVERSE_FC2=0 disables)
+    int order_mask = 8;               // tile walk last-to-first per GEMM: bit0 qkv, bit1 proj, bit2 fc1, bit3 fc2 (VP_ORDER)
     bool blocked_hid = true;          // mlp hidden activations in the 64x64-blocked layout (VP_BLOCKED_HID=0: row-major)
     bool fuse_ln = true;              // LayerNorm folded into the GEMMs on both sides of it (VP_FUSE_LN=0: standalone passes)
     float *ln_part = nullptr, *rowstat = nullptr;   // partial row statistics [M][D/64][2], (mean, rstd) [M][2]
@@ -388,15 +388,16 @@ int forward_chunk(vp_ctx* c, const void* d_crops, int fmt, int n, bool want_toke
         if ((rc = finalize())) return rc;
         for (int l = 0; l < c->L; ++l) {
             const Block& b = c->blocks[l];
-            LnFuse cq; cq.rowstat = c->rowstat; cq.ln_s = b.s_qkv;
+            LnFuse cq; cq.rowstat = c->rowstat; cq.ln_s = b.s_qkv; cq.reverse = (c->order_mask & 1) != 0;
             if ((rc = gemm(c, VP_PROF_GEMM_QKV, vp::EPI_BIAS, xh, b.w_qkv, b.b_qkv, c->qkv, nullptr, M, 3 * D, D, 3 * D, 0, 0, 0, &cq))) return rc;
             LAUNCH(c, VP_PROF_ATTN, 4.0 * 192 * 192 * (double)D * n, 8.0 * M * D,
                    vp::attention_launch(c->dtype, c->qkv, c->y, n, D, c->heads, c->stream));
-            if ((rc = gemm(c, VP_PROF_GEMM_PROJ, vp::EPI_BIAS_RESID_LN, c->y, b.w_proj, b.b_proj, c->x, c->x, M, D, D, D, 0, 0, 0, &prod))) return rc;
+            LnFuse pp = prod; pp.reverse = (c->order_mask & 2) != 0;
+            if ((rc = gemm(c, VP_PROF_GEMM_PROJ, vp::EPI_BIAS_RESID_LN, c->y, b.w_proj, b.b_proj, c->x, c->x, M, D, D, D, 0, 0, 0, &pp))) return rc;
             if ((rc = finalize())) return rc;
-            LnFuse c1; c1.rowstat = c->rowstat; c1.ln_s = b.s_fc1; c1.out_blocked = c->blocked_hid;
+            LnFuse c1; c1.rowstat = c->rowstat; c1.ln_s = b.s_fc1; c1.out_blocked = c->blocked_hid; c1.reverse = (c->order_mask & 4) != 0;
             if ((rc = gemm(c, VP_PROF_GEMM_FC1, vp::EPI_BIAS_GELU, xh, b.w_fc1, b.b_fc1, c->hid, nullptr, M, 4 * D, D, 4 * D, 0, 0, 0, &c1))) return rc;
-            LnFuse p2 = prod; p2.a_blocked = c->blocked_hid; p2.reverse = c->reverse_fc2;
+            LnFuse p2 = prod; p2.a_blocked = c->blocked_hid; p2.reverse = (c->order_mask & 8) != 0;
             if ((rc = gemm(c, VP_PROF_GEMM_PROJ, vp::EPI_BIAS_RESID_LN, c->hid, b.w_fc2, b.b_fc2, c->x, c->x, M, D, 4 * D, D, 0, 0, 0, &p2))) return rc;
             if (l + 1 < c->L && (rc = finalize())) return rc;   // last block: last_norm below is a standalone pass
         }
@@ -485,7 +486,7 @@ int vp_create(vp_handle* out, const vp_config* cfg) {
     if ((rc = dalloc(c, &c->y, M * D))) return bail(rc);
     if (const char* f = getenv("VP_FUSE_LN")) c->fuse_ln = atoi(f) != 0;
     if (const char* f = getenv("VP_BLOCKED_HID")) c->blocked_hid = atoi(f) != 0;
-    if (const char* f = getenv("VP_REVERSE_FC2")) c->reverse_fc2 = atoi(f) != 0;
+    if (const char* f = getenv("VP_ORDER")) c->order_mask = atoi(f);
     if (c->fuse_ln) {
         if ((rc = dalloc(c, &c->ln_part, M * (size_t)(D / 64) * 2))) return bail(rc);
         if ((rc = dalloc(c, &c->rowstat, M * 2))) return bail(rc);
