@@ -741,6 +741,244 @@ __global__ __launch_bounds__(C::NT, 2) void gemm_kernel(GemmArgs g) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Persistent variant for the wide GEMMs with a 16-bit output (qkv: EPI_BIAS, fc1: EPI_BIAS_GELU; dense A, BK = 64,
+// two-stage ring, K a multiple of 128).  A workgroup walks a strided list of tiles and the operand ring simply
+// runs on across the tile boundary:
+//   * in the LAST k-step of a tile the staging addresses switch to the next tile and its k-block 0 streams into ring
+//     buffer 0, so the prologue latency (~1.5 us of a ~10 us tile) is covered by that k-step and the epilogue;
+//   * the epilogue stages the C tile in ring buffer 1 only, waits for the prefetched k-block BEFORE it issues its
+//     global stores, and the next tile's first k-step needs no vmcnt wait: the store acknowledgements drain behind
+//     a whole k-step of MFMAs instead of in front of a workgroup exit + relaunch.
+// Ordering argument (everything below follows from it): a global_load_lds into buffer b is only issued after a
+// barrier that every wave passes after its last read of b; a read of b only happens after the issuing waves'
+// vmcnt(0) AND a later barrier.  Buffer 1 <- staged C rows after the barrier that ends the main loop; the next
+// tile's k-block 1 goes into buffer 1 after that tile's first barrier, which every wave reaches after its last
+// read of the staged rows.
+// Tile schedule: XCD x (= blockIdx.x & 7) owns a contiguous range of the (grouped) tile order, its workgroups
+// take it round-robin -- at any time the resident workgroups of an XCD work on consecutive tiles, as in the
+// one-tile-per-workgroup launch.
+template <class T, int EPI, class C>
+__global__ __launch_bounds__(C::NT, 2) void gemm_persist_kernel(GemmArgs g) {
+    static_assert(C::BK == 64 && C::STAGES == 2 && C::PIPE == 1 && (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU), "persistent variant");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tiles_n = (g.N + C::BN - 1) / C::BN;
+    const int tiles_m = (g.M + C::BM - 1) / C::BM;
+    const int ntiles = tiles_m * tiles_n;
+    const int K = g.K, nk = K / C::BK;
+    // this workgroup's tiles: base + j, base + j + nloc, ...
+    const int xcd = blockIdx.x & 7, j0 = blockIdx.x >> 3, nloc = gridDim.x >> 3;
+    const int q = ntiles >> 3, r8 = ntiles & 7;
+    const int base = (xcd < r8) ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q;
+    const int cnt = q + (xcd < r8 ? 1 : 0);
+    if (j0 >= cnt) return;
+    auto tile_origin = [&](int t, int& m0, int& n0) {
+        const int bid = base + t;
+        int tm, tn;
+        if (g.group_m > 1) {
+            const int per_group = g.group_m * tiles_n;
+            const int grp = bid / per_group, first_m = grp * g.group_m;
+            const int gsz = min(tiles_m - first_m, g.group_m);
+            const int r = bid - grp * per_group;
+            tm = first_m + r % gsz;
+            tn = r / gsz;
+        } else {
+            tm = bid / tiles_n;
+            tn = bid - tm * tiles_n;
+        }
+        m0 = tm * C::BM;
+        n0 = tn * C::BN;
+    };
+    // Staging addresses = wave-uniform base (SGPRs: tile, piece, k-step) + ONE per-lane byte offset that never
+    // changes: row (p NWAVES + wave) 8 + rip of the tile, 16-byte slot pslot ^ ((row >> 1) & 7) -- and (row >> 1) & 7
+    // = 4 (wave & 1) + (rip >> 1) for every piece p (NWAVES is even).  Keeps the tile loop out of the VGPR budget.
+    static_assert(C::RPG == 8 && C::NWAVES % 2 == 0, "address split assumes 8 rows per piece and an even wave count");
+    const int rip = lane >> 3, pslot = lane & 7;
+    const int sw = pslot ^ (((wave & 1) << 2) | (rip >> 1));
+    const uint32_t voff_w = (uint32_t)(rip * K + sw * 8) * 2u;
+    const uint32_t voff_a = g.a_blocked ? (uint32_t)(rip * 64 + sw * 8) * 2u : voff_w;
+    const char* wbase = nullptr;   // W + (n0 + wave 8) K        (wave-uniform)
+    const char* abase = nullptr;   // A + (m0 + wave 8) K, or the 64x64 block of row m0 + wave 8
+    auto set_addr = [&](int m0, int n0) {
+        wbase = (const char*)(g.W + (size_t)(n0 + wave * 8) * K);
+        abase = g.a_blocked ? (const char*)(g.A + ((size_t)(m0 >> 6) * (K >> 6) << 12))
+                            : (const char*)(g.A + (size_t)(m0 + wave * 8) * K);
+    };
+    auto stage = [&](int kt, int buf) {
+        char* sbase = smem + buf * C::STAGE_BYTES + wave * 1024;
+        const int k0 = kt * C::BK;
+#pragma unroll
+        for (int p = 0; p < C::WP; ++p)
+            glds16(wbase + ((size_t)(p * C::NWAVES * 8) * K + k0) * 2 + voff_w, sbase + p * (C::NWAVES * 1024));
+#pragma unroll
+        for (int p = 0; p < C::AP; ++p) {
+            const char* pa;
+            if (g.a_blocked) {   // piece rows (p NWAVES + wave) 8 .. + 7 of the tile: block row (..) >> 3, row (..) & 7 inside it
+                const int pr = p * C::NWAVES + wave;
+                pa = abase + ((((size_t)(pr >> 3) * (K >> 6) + (k0 >> 6)) << 12) + ((pr & 7) << 9)) * 2;
+            } else {
+                pa = abase + ((size_t)(p * C::NWAVES * 8) * K + k0) * 2;
+            }
+            glds16(pa + voff_a, sbase + C::W_BYTES + p * (C::NWAVES * 1024));
+        }
+    };
+    const int wn = wave / C::NWM, wm = wave % C::NWM;
+    const int frow = lane & 15, fg = lane >> 4;
+    const int foff = frow * C::ROWB + (swz<C::BK>(frow, fg) << 4);
+    const int woff = wn * C::WN * C::ROWB + foff;
+    const int aoff = C::W_BYTES + wm * C::WM * C::ROWB + foff;
+
+    // epilogue geometry: C rows staged in ring buffer 1
+    constexpr int ROWBYTES = C::BN * 2 + 16;
+    constexpr int JP = [] { int jp = C::TJ; while (jp > 1 && (C::TJ % jp || C::NWM * jp * 16 * ROWBYTES > C::STAGE_BYTES)) --jp; return jp; }();
+    constexpr int CR = C::NWM * JP * 16, CPR = C::BN / 8, NCH = CR * CPR / C::NT;
+    static_assert(C::TJ % JP == 0 && NCH * C::NT == CR * CPR && CR * ROWBYTES <= C::STAGE_BYTES, "epilogue staging must fit one ring buffer");
+    char* cst = smem + C::STAGE_BYTES;
+    const bool ln_in = g.rowstat != nullptr;
+
+    int t = j0, m0, n0;
+    tile_origin(t, m0, n0);
+    set_addr(m0, n0);
+    stage(0, 0);
+    bool landed = false;   // k-block 0 of the current tile already waited for (by the previous tile's epilogue)
+    for (;;) {
+        f32x4 acc[C::TI][C::TJ];
+#pragma unroll
+        for (int i = 0; i < C::TI; ++i)
+#pragma unroll
+            for (int j = 0; j < C::TJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        int nm0 = 0, nn0 = 0;
+        bool has_next = false;
+        for (int kt = 0; kt < nk; ++kt) {
+            if (kt > 0 || !landed) wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (kt + 1 < nk) {
+                stage(kt + 1, (kt + 1) & 1);
+            } else {
+                has_next = t + nloc < cnt;
+                if (has_next) {
+                    tile_origin(t + nloc, nm0, nn0);
+                    set_addr(nm0, nn0);
+                    stage(0, 0);
+                }
+            }
+            const char* sb = smem + (kt & 1) * C::STAGE_BYTES;
+            u32x4 wf0[C::TI], af0[C::TJ], wf1[C::TI], af1[C::TJ];
+#pragma unroll
+            for (int i = 0; i < C::TI; ++i) wf0[i] = *(const u32x4*)(sb + (woff + i * 16 * C::ROWB));
+#pragma unroll
+            for (int j = 0; j < C::TJ; ++j) af0[j] = *(const u32x4*)(sb + (aoff + j * 16 * C::ROWB));
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int i = 0; i < C::TI / 2; ++i)
+#pragma unroll
+                for (int j = 0; j < C::TJ; ++j) acc[i][j] = mfma16<T>(wf0[i], af0[j], acc[i][j]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < C::TI; ++i) wf1[i] = *(const u32x4*)(sb + ((woff + i * 16 * C::ROWB) ^ 64));
+#pragma unroll
+            for (int j = 0; j < C::TJ; ++j) af1[j] = *(const u32x4*)(sb + ((aoff + j * 16 * C::ROWB) ^ 64));
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = C::TI / 2; i < C::TI; ++i)
+#pragma unroll
+                for (int j = 0; j < C::TJ; ++j) acc[i][j] = mfma16<T>(wf0[i], af0[j], acc[i][j]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < C::TI; ++i)
+#pragma unroll
+                for (int j = 0; j < C::TJ; ++j) acc[i][j] = mfma16<T>(wf1[i], af1[j], acc[i][j]);
+            __builtin_amdgcn_s_setprio(0);
+        }
+
+        // ---- epilogue of tile (m0, n0): bias / LayerNorm consumer / GELU, staged through ring buffer 1 ----
+        f32x4 bias4[C::TI], ln_s4[C::TI];
+        float ln_mean[C::TJ], ln_rstd[C::TJ];
+#pragma unroll
+        for (int i = 0; i < C::TI; ++i) bias4[i] = *(const f32x4*)(g.bias + n0 + wn * C::WN + i * 16 + fg * 4);
+        if (ln_in) {
+#pragma unroll
+            for (int i = 0; i < C::TI; ++i) ln_s4[i] = *(const f32x4*)(g.ln_s + n0 + wn * C::WN + i * 16 + fg * 4);
+#pragma unroll
+            for (int j = 0; j < C::TJ; ++j) {
+                int m = m0 + wm * C::WM + j * 16 + frow;
+                if (m > g.M - 1) m = g.M - 1;
+                ln_mean[j] = g.rowstat[2 * (size_t)m];
+                ln_rstd[j] = g.rowstat[2 * (size_t)m + 1];
+            }
+        }
+        __syncthreads();   // every wave is done reading ring buffer 1 (the last k-block)
+#pragma unroll
+        for (int p = 0; p < C::TJ / JP; ++p) {
+#pragma unroll
+            for (int jj = 0; jj < JP; ++jj) {
+                char* lrow = cst + ((wm * JP + jj) * 16 + frow) * ROWBYTES + (wn * C::WN + fg * 4) * 2;
+#pragma unroll
+                for (int i = 0; i < C::TI; ++i) {
+                    f32x4 v = acc[i][p * JP + jj];
+                    if (ln_in) {
+                        const float mu = ln_mean[p * JP + jj], rs = ln_rstd[p * JP + jj];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = (v[r] - mu * ln_s4[i][r]) * rs;
+                    }
+                    v += bias4[i];
+                    if (EPI == EPI_BIAS_GELU) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+                    }
+                    u32x2 o;
+                    o[0] = pack2<T>(v[0], v[1]);
+                    o[1] = pack2<T>(v[2], v[3]);
+                    *(u32x2*)(lrow + i * 32) = o;
+                }
+            }
+            if (p == 0) wait_vmcnt<0>();   // the next tile's k-block 0 has landed (own share) -- BEFORE any store is in flight
+            __syncthreads();
+#pragma unroll
+            for (int qq = 0; qq < NCH; ++qq) {
+                const int c = tid + qq * C::NT;
+                const int lr = c / CPR, ch = c - lr * CPR;
+                const int wmr = lr / (JP * 16), rr = lr - wmr * (JP * 16);
+                const int m = m0 + wmr * C::WM + p * JP * 16 + rr;
+                const int n = n0 + ch * 8;
+                if (m >= g.M || n >= g.N) continue;
+                const u32x4 v = *(const u32x4*)(cst + lr * ROWBYTES + ch * 16);
+                uint16_t* dst = g.out_blocked
+                    ? (uint16_t*)g.out + (((size_t)(m >> 6) * (g.ldo >> 6) + (n >> 6)) << 12) + ((m & 63) << 6) + (n & 63)
+                    : (uint16_t*)g.out + (size_t)m * g.ldo + n;
+                *(u32x4*)dst = v;
+            }
+            if (p + 1 < C::TJ / JP) __syncthreads();
+        }
+        if (!has_next) break;
+        t += nloc;
+        m0 = nm0;
+        n0 = nn0;
+        landed = true;
+    }
+}
+
+template <class T, int EPI, class C>
+static hipError_t launch_persist(const GemmArgs& a, hipStream_t s) {
+    auto kern = gemm_persist_kernel<T, EPI, C>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    const int tiles = ((a.M + C::BM - 1) / C::BM) * ((a.N + C::BN - 1) / C::BN);
+    const int resident = 256 * (160 * 1024 / C::LDS);           // workgroups the chip holds at once
+    int grid = tiles < resident ? tiles : resident;
+    grid &= ~7;
+    if (grid < 8) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(C::NT), C::LDS, s, a);
+    return hipGetLastError();
+}
+
 // Tile configurations (id = GemmArgs::variant).  Measured on MI355X at M = 49152 (tools/gemm_tune.py,
 // profiles/gemm_tune_r1.txt).  Default = Cfg8: one 192-token crop per m-tile, so the tile count divides
 // evenly over 256 CUs x 2 resident blocks for every encoder GEMM (no tail wave), and the epilogue of one
@@ -828,8 +1066,15 @@ int gemm_tile_bn(int variant) {
 
 hipError_t gemm_launch(int dtype, int epi, const GemmArgs& a, hipStream_t s) {
     if (a.K % 64 != 0 || a.M <= 0 || a.N <= 0) return hipErrorInvalidValue;
-    if (epi == EPI_DECONV && (a.Cin % 64 != 0 || a.K != 4 * a.Cin)) return hipErrorInvalidValue;
-    if (epi != EPI_HEATMAP && (a.N % 4 != 0 || a.ldo % 4 != 0)) return hipErrorInvalidValue;  // 8/16-byte epilogue stores
+    if (a.persist) {   // persistent variant: wide 16-bit-output GEMMs on the default tile (a 256x256 instantiation spilled and was slower)
+        if ((epi != EPI_BIAS && epi != EPI_BIAS_GELU) || a.variant != 8 || a.K % 128 || a.N % 8 || a.ldo != a.N || a.reverse ||
+            a.M % Cfg8::BM || (size_t)a.M * a.K * 2 >= (1ull << 32) ||
+            (size_t)((a.N + Cfg8::BN - 1) / Cfg8::BN) * Cfg8::BN > (size_t)a.w_rows)
+            return hipErrorInvalidValue;
+        if (dtype == DT_F16)
+            return epi == EPI_BIAS ? launch_persist<F16, EPI_BIAS, Cfg8>(a, s) : launch_persist<F16, EPI_BIAS_GELU, Cfg8>(a, s);
+        return epi == EPI_BIAS ? launch_persist<BF16, EPI_BIAS, Cfg8>(a, s) : launch_persist<BF16, EPI_BIAS_GELU, Cfg8>(a, s);
+    }
     if (a.a_blocked && (epi == EPI_DECONV || (a.M & 63))) return hipErrorInvalidValue;
     if (a.out_blocked && ((epi != EPI_BIAS && epi != EPI_BIAS_GELU) || (a.M & 63) || (a.N & 63) || a.ldo != a.N)) return hipErrorInvalidValue;
     if ((epi == EPI_BIAS_RESID_LN || epi == EPI_POS_LN) && (a.N % 64 != 0 || !a.plane || !a.stats_out)) return hipErrorInvalidValue;

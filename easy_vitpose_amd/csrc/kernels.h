@@ -54,6 +54,9 @@ struct GemmArgs {
     // tile order last-to-first: a consumer of a tensor larger than the 256 MB Infinity Cache then starts with the
     // rows its producer wrote last (still cached) instead of the ones already evicted
     int reverse;
+    // persistent workgroups whose operand ring runs on across tile boundaries (gemm.hip gemm_persist_kernel):
+    // EPI_BIAS / EPI_BIAS_GELU on the default tile, K % 128 == 0
+    int persist;
     int ablate;           // profiling only (tools/gemm_ablate.py): 1 = no operand loads after the prologue, 2 = every tile loads the A rows of m-tile 0 (A L2-resident), 8 = no epilogue stores
 };
 hipError_t gemm_launch(int dtype, int epi, const GemmArgs& a, hipStream_t s);

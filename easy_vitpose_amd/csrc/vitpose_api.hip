@@ -79,6 +79,7 @@ struct vp_ctx {
     float* x = nullptr;
     uint16_t *y = nullptr, *qkv = nullptr, *hid = nullptr, *d1 = nullptr, *d2 = nullptr;
     float *hm = nullptr, *kp = nullptr, *tok = nullptr;
+    bool persist_gemm = true;         // qkv / fc1 as persistent workgroups at large batch (VP_PERSIST=0: one tile per workgroup)
     int order_mask = 8;               // tile walk last-to-first per GEMM: bit0 qkv, bit1 proj, bit2 fc1, bit3 fc2 (VP_ORDER)
     bool blocked_hid = true;          // mlp hidden activations in the 64x64-blocked layout (VP_BLOCKED_HID=0: row-major)
     bool fuse_ln = true;              // LayerNorm folded into the GEMMs on both sides of it (VP_FUSE_LN=0: standalone passes)
@@ -344,6 +345,9 @@ int gemm(vp_ctx* c, int fam, int epi, const uint16_t* A, const uint16_t* W, cons
         const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128) * par_;
         if (t192 < 384) { g.variant = (t128 >= 256) ? 1 : 9; g.group_m = 0; }
     }
+    if (c->persist_gemm && g.variant == 8 && (epi == vp::EPI_BIAS || epi == vp::EPI_BIAS_GELU) && K % 128 == 0 && ldo == N &&
+        M % 192 == 0 && N % 128 == 0 && (long)(M / 192) * (N / 128) >= 1024)   // >= 2 tiles per resident workgroup
+        g.persist = 1;
     if (ln) {
         g.a_blocked = ln->a_blocked; g.out_blocked = ln->out_blocked; g.reverse = ln->reverse;
         g.plane = ln->plane; g.stats_out = ln->stats_out; g.rowstat = ln->rowstat; g.ln_s = ln->ln_s;
@@ -487,6 +491,7 @@ int vp_create(vp_handle* out, const vp_config* cfg) {
     if (const char* f = getenv("VP_FUSE_LN")) c->fuse_ln = atoi(f) != 0;
     if (const char* f = getenv("VP_BLOCKED_HID")) c->blocked_hid = atoi(f) != 0;
     if (const char* f = getenv("VP_ORDER")) c->order_mask = atoi(f);
+    if (const char* f = getenv("VP_PERSIST")) c->persist_gemm = atoi(f) != 0;
     if (c->fuse_ln) {
         if ((rc = dalloc(c, &c->ln_part, M * (size_t)(D / 64) * 2))) return bail(rc);
         if ((rc = dalloc(c, &c->rowstat, M * 2))) return bail(rc);

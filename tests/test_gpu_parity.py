@@ -177,6 +177,22 @@ def test_baseline_batch_properties():
     eng.close()
 
 
+def test_persistent_gemm_is_bit_identical(monkeypatch):
+    """qkv / fc1 run as persistent workgroups (operand ring carried across tile boundaries) once a launch has >= 1024
+    tiles; the arithmetic per tile is unchanged, so keypoints must be bit-identical to the one-tile-per-workgroup
+    launch -- repeated, because a ring/barrier race would show up as run-to-run differences."""
+    shp, sd, _ = weights('b', 'coco')
+    crops = synthetic_crops(64, 21, 'noise')          # 64 x 18 = 1152 qkv tiles, 1536 fc1 tiles
+    out = {}
+    for flag in ('0', '1'):
+        monkeypatch.setenv('VP_PERSIST', flag)
+        eng = VitPoseHip(shp, sd, dtype='fp16', max_batch=64)
+        out[flag] = [eng.infer(crops) for _ in range(4)]
+        eng.close()
+    for o in out['0'][1:] + out['1']:
+        assert np.array_equal(o, out['0'][0])
+
+
 # ------------------------------------------------------------------- VitInference API
 def test_vitinference_surface_with_fake_detector():
     shp, sd, sdt = weights('s', 'coco')
