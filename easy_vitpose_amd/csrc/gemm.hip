@@ -850,6 +850,8 @@ __global__ __launch_bounds__(C::NT, 2) void gemm_persist_kernel(GemmArgs g) {
             for (int j = 0; j < C::TJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
         int nm0 = 0, nn0 = 0;
         bool has_next = false;
+        unsigned long long ts0 = 0, ts1 = 0;
+        if (g.ablate & 32) ts0 = __builtin_readcyclecounter();   // tools/gemm_timeline.py: per-tile phase stamps of wave 0
         for (int kt = 0; kt < nk; ++kt) {
             if (kt > 0 || !landed) wait_vmcnt<0>();
             __builtin_amdgcn_s_barrier();
@@ -894,6 +896,7 @@ __global__ __launch_bounds__(C::NT, 2) void gemm_persist_kernel(GemmArgs g) {
             __builtin_amdgcn_s_setprio(0);
         }
 
+        if (g.ablate & 32) ts1 = __builtin_readcyclecounter();
         // ---- epilogue of tile (m0, n0): bias / LayerNorm consumer / GELU, staged through ring buffer 1 ----
         f32x4 bias4[C::TI], ln_s4[C::TI];
         float ln_mean[C::TJ], ln_rstd[C::TJ];
@@ -952,6 +955,10 @@ __global__ __launch_bounds__(C::NT, 2) void gemm_persist_kernel(GemmArgs g) {
                 *(u32x4*)dst = v;
             }
             if (p + 1 < C::TJ / JP) __syncthreads();
+        }
+        if ((g.ablate & 32) && tid == 0) {
+            unsigned long long* st = (unsigned long long*)g.stats_out + ((size_t)blockIdx.x * 32 + (t - j0) / nloc) * 3;
+            st[0] = ts0; st[1] = ts1; st[2] = __builtin_readcyclecounter();
         }
         if (!has_next) break;
         t += nloc;

@@ -875,6 +875,37 @@ VP_API int vp_dbg_deconv(int32_t device, int32_t dtype, int32_t B, int32_t Hin, 
 
 // Time `iters` launches of one GEMM configuration on random device operands (HIP events).
 // epi as in vp_dbg_gemm (0..3); returns average milliseconds per launch in *ms_out.
+// tools/gemm_timeline.py: one persistent launch of the qkv / fc1 shape with per-tile phase stamps (shader cycles) of wave 0 of
+// every workgroup: stamps[wg][tile][3] = (main loop start, main loop end, epilogue end), up to 32 tiles per workgroup.
+VP_API int vp_dbg_gemm_timeline(int32_t device, int32_t dtype, int32_t epi, int32_t M, int32_t N, int32_t K, uint64_t* stamps,
+                                int32_t max_wg) {
+    if ((epi != 0 && epi != 1) || !stamps) return fail(nullptr, VP_ERR_INVALID, "bad timeline request");
+    vp_ctx* c = dbg_ctx(device, dtype);
+    if (!c) return VP_ERR_HIP;
+    uint16_t *dA, *dW, *dO;
+    float* dB;
+    unsigned long long* dS;
+    int rc;
+    const size_t wrows = pad128(N), nst = (size_t)max_wg * 32 * 3;
+    if ((rc = dalloc(c, &dA, (size_t)M * K)) || (rc = dalloc(c, &dW, wrows * K)) || (rc = dalloc(c, &dB, wrows)) ||
+        (rc = dalloc(c, &dO, (size_t)M * N)) || (rc = dalloc(c, &dS, nst)) || (rc = dalloc(c, &c->zero, (size_t)256)))
+        return dbg_finish(c, rc);
+    vp::fill_random16(c->dtype, dA, (size_t)M * K, 1u, nullptr);
+    vp::fill_random16(c->dtype, dW, wrows * K, 2u, nullptr);
+    hipMemset(dB, 0, wrows * 4);
+    hipMemset(dS, 0, nst * 8);
+    vp::GemmArgs g{};
+    g.A = dA; g.W = dW; g.bias = dB; g.out = dO; g.M = M; g.N = N; g.K = K; g.ldo = N; g.zero = c->zero;
+    g.w_rows = (int)wrows; g.variant = 8; g.group_m = 8; g.persist = 1;
+    hipError_t e = vp::gemm_launch(c->dtype, epi, g, nullptr);          // warm
+    g.ablate = 32; g.stats_out = (float*)dS;
+    if (e == hipSuccess) e = vp::gemm_launch(c->dtype, epi, g, nullptr);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipMemcpy(stamps, dS, nst * 8, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return dbg_finish(c, fail(c, VP_ERR_HIP, std::string("timeline: ") + hipGetErrorString(e)));
+    return dbg_finish(c, VP_OK);
+}
+
 VP_API int vp_dbg_gemm_bench(int32_t device, int32_t dtype, int32_t epi, int32_t variant, int32_t group_m, int32_t M,
                              int32_t N, int32_t K, int32_t iters, float* ms_out) {
     if (epi < 0 || epi > 3 || M <= 0 || N <= 0 || K <= 0 || K % 64 || iters <= 0 || !ms_out)
