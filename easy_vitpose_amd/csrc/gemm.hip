@@ -901,7 +901,7 @@ __global__ __launch_bounds__(C::NT, 2) void gemm_persist_kernel(GemmArgs g) {
         f32x4 bias4[C::TI], ln_s4[C::TI];
         float ln_mean[C::TJ], ln_rstd[C::TJ];
 #pragma unroll
-        for (int i = 0; i < C::TI; ++i) bias4[i] = *(const f32x4*)(g.bias + n0 + wn * C::WN + i * 16 + fg * 4);
+        for (int i = 0; i < C::TI; ++i) bias4[i] = (g.ablate & 64) ? f32x4{0.f, 0.f, 0.f, 0.f} : *(const f32x4*)(g.bias + n0 + wn * C::WN + i * 16 + fg * 4);
         if (ln_in) {
 #pragma unroll
             for (int i = 0; i < C::TI; ++i) ln_s4[i] = *(const f32x4*)(g.ln_s + n0 + wn * C::WN + i * 16 + fg * 4);

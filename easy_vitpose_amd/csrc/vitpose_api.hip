@@ -898,7 +898,7 @@ VP_API int vp_dbg_gemm_timeline(int32_t device, int32_t dtype, int32_t epi, int3
     g.A = dA; g.W = dW; g.bias = dB; g.out = dO; g.M = M; g.N = N; g.K = K; g.ldo = N; g.zero = c->zero;
     g.w_rows = (int)wrows; g.variant = 8; g.group_m = 8; g.persist = 1;
     hipError_t e = vp::gemm_launch(c->dtype, epi, g, nullptr);          // warm
-    g.ablate = 32; g.stats_out = (float*)dS;
+    g.ablate = 32 | (getenv("VP_TL_ABL") ? atoi(getenv("VP_TL_ABL")) : 0); g.stats_out = (float*)dS;
     if (e == hipSuccess) e = vp::gemm_launch(c->dtype, epi, g, nullptr);
     if (e == hipSuccess) e = hipDeviceSynchronize();
     if (e == hipSuccess) e = hipMemcpy(stamps, dS, nst * 8, hipMemcpyDeviceToHost);
