@@ -24,6 +24,7 @@
 //    output-parity classes, each a GEMM with K = 4*Cin whose A rows are gathered
 //    (one row chunk per k-step, zero row at the border) straight by the
 //    global_load_lds source addresses -- no im2col buffer in HBM.
+#include <type_traits>
 #include <utility>
 
 #include "common.h"

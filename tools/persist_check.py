@@ -33,7 +33,8 @@ for variant, batch in (('b', 64), ('b', 256), ('s', 128), ('l', 96)):
         hashes[flag] = [l for l in res.stdout.split() if len(l) == 16]
         if res.returncode != 0:
             print(res.stderr[-2000:])
-    same = len(set(hashes['0'] + hashes['1'])) == 1 and len(hashes['1']) == 6
+    allh = sum(hashes.values(), [])
+    same = len(set(allh)) == 1 and all(len(v) == 6 for v in hashes.values())
     ok &= same
-    print(f'ViTPose-{variant.upper()} batch {batch}: persist=0 {set(hashes["0"])} persist=1 {set(hashes["1"])} -> {"IDENTICAL" if same else "MISMATCH"}')
+    print(f'ViTPose-{variant.upper()} batch {batch}: ' + ' '.join(f'persist={k} {sorted(set(v))}' for k, v in hashes.items()) + f' -> {"IDENTICAL" if same else "MISMATCH"}')
 sys.exit(0 if ok else 1)
