@@ -62,6 +62,25 @@ def _engine(variant, dataset, dtype, max_batch=8):
     return VitPoseHip(shp, sd, dtype=dtype, device_id=0, max_batch=max_batch)
 
 
+@pytest.mark.parametrize('variant,dataset,n', [('l', 'coco_25', 2), ('h', 'wholebody', 2)])
+def test_large_variants_parity_vs_oracle(variant, dataset, n):
+    """ViTPose-L (D = 1024, 24 blocks, K = 25) and ViTPose-H (head dim 80, 32 blocks, K = 133 -> three n-tiles of hi+lo
+    final-conv weights): heatmaps and confidences against the oracle on fresh crops (the goldens hold one crop each)."""
+    crops = synthetic_crops(n, 17, 'blobs')
+    ref_hm = oracle_heatmaps(variant, dataset, crops, chunk=1)
+    eng = _engine(variant, dataset, 'fp16', max_batch=n)
+    hm = eng.heatmaps(crops)
+    err = np.abs(hm - ref_hm)
+    print(f'[{variant}/fp16] heatmap std {ref_hm.std():.3f}  max|err| {err.max():.3e}  rms {np.sqrt((err ** 2).mean()):.3e}')
+    assert err.max() < HM_MAX_ERR['fp16'] and np.sqrt((err ** 2).mean()) < HM_RMS_ERR['fp16']
+    kp = eng.infer(crops)
+    ref_kp = O.decode_per_crop(ref_hm)
+    cerr = np.abs(kp[..., 2] - ref_kp[..., 2]).max()
+    print(f'[{variant}/fp16] confidence max err {cerr:.3e}')
+    assert cerr < 1.5 * CONF_TOL   # K = 133 x deeper stacks: more joints, one more sigma of the same error distribution
+    eng.close()
+
+
 @pytest.mark.parametrize('dtype', ['fp16', 'bf16'])
 @pytest.mark.parametrize('variant,dataset,n', [('s', 'coco', 16), ('b', 'coco', 8)])
 def test_model_parity_vs_oracle(variant, dataset, n, dtype):
