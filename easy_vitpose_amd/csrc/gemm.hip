@@ -851,12 +851,15 @@ __global__ __launch_bounds__(C::NT, 2) void gemm_persist_kernel(GemmArgs g) {
             for (int j = 0; j < C::TJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
         int nm0 = 0, nn0 = 0;
         bool has_next = false;
-        unsigned long long ts0 = 0, ts1 = 0;
+        unsigned long long ts0 = 0, ts1 = 0, ks[5] = {0, 0, 0, 0, 0};
         if (g.ablate & 32) ts0 = __builtin_readcyclecounter();   // tools/gemm_timeline.py: per-tile phase stamps of wave 0
         for (int kt = 0; kt < nk; ++kt) {
+            const bool stamp = (g.ablate & 32) && kt == 5;        // ... and the phases inside k-step 5
+            if (stamp) ks[0] = __builtin_readcyclecounter();
             if (kt > 0 || !landed) wait_vmcnt<0>();
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
+            if (stamp) ks[1] = __builtin_readcyclecounter();
             if (kt + 1 < nk) {
                 stage(kt + 1, (kt + 1) & 1);
             } else {
@@ -867,6 +870,7 @@ __global__ __launch_bounds__(C::NT, 2) void gemm_persist_kernel(GemmArgs g) {
                     stage(0, 0);
                 }
             }
+            if (stamp) ks[2] = __builtin_readcyclecounter();
             const char* sb = smem + (kt & 1) * C::STAGE_BYTES;
             u32x4 wf0[C::TI], af0[C::TJ], wf1[C::TI], af1[C::TJ];
 #pragma unroll
@@ -880,6 +884,7 @@ __global__ __launch_bounds__(C::NT, 2) void gemm_persist_kernel(GemmArgs g) {
 #pragma unroll
                 for (int j = 0; j < C::TJ; ++j) acc[i][j] = mfma16<T>(wf0[i], af0[j], acc[i][j]);
             __builtin_amdgcn_sched_barrier(0);
+            if (stamp) ks[3] = __builtin_readcyclecounter();
 #pragma unroll
             for (int i = 0; i < C::TI; ++i) wf1[i] = *(const u32x4*)(sb + ((woff + i * 16 * C::ROWB) ^ 64));
 #pragma unroll
@@ -895,6 +900,7 @@ __global__ __launch_bounds__(C::NT, 2) void gemm_persist_kernel(GemmArgs g) {
 #pragma unroll
                 for (int j = 0; j < C::TJ; ++j) acc[i][j] = mfma16<T>(wf1[i], af1[j], acc[i][j]);
             __builtin_amdgcn_s_setprio(0);
+            if (stamp) ks[4] = __builtin_readcyclecounter();
         }
 
         if (g.ablate & 32) ts1 = __builtin_readcyclecounter();
@@ -958,8 +964,10 @@ __global__ __launch_bounds__(C::NT, 2) void gemm_persist_kernel(GemmArgs g) {
             if (p + 1 < C::TJ / JP) __syncthreads();
         }
         if ((g.ablate & 32) && tid == 0) {
-            unsigned long long* st = (unsigned long long*)g.stats_out + ((size_t)blockIdx.x * 32 + (t - j0) / nloc) * 3;
+            unsigned long long* st = (unsigned long long*)g.stats_out + ((size_t)blockIdx.x * 32 + (t - j0) / nloc) * 8;
             st[0] = ts0; st[1] = ts1; st[2] = __builtin_readcyclecounter();
+#pragma unroll
+            for (int e = 0; e < 5; ++e) st[3 + e] = ks[e];
         }
         if (!has_next) break;
         t += nloc;

@@ -876,7 +876,8 @@ VP_API int vp_dbg_deconv(int32_t device, int32_t dtype, int32_t B, int32_t Hin, 
 // Time `iters` launches of one GEMM configuration on random device operands (HIP events).
 // epi as in vp_dbg_gemm (0..3); returns average milliseconds per launch in *ms_out.
 // tools/gemm_timeline.py: one persistent launch of the qkv / fc1 shape with per-tile phase stamps (shader cycles) of wave 0 of
-// every workgroup: stamps[wg][tile][3] = (main loop start, main loop end, epilogue end), up to 32 tiles per workgroup.
+// every workgroup: stamps[wg][tile][8] = (main loop start, main loop end, epilogue end, 5 stamps inside k-step 5: top, after the
+// barrier, after the global_load_lds issues, after the first MFMA block, end), up to 32 tiles per workgroup.
 VP_API int vp_dbg_gemm_timeline(int32_t device, int32_t dtype, int32_t epi, int32_t M, int32_t N, int32_t K, uint64_t* stamps,
                                 int32_t max_wg) {
     if ((epi != 0 && epi != 1) || !stamps) return fail(nullptr, VP_ERR_INVALID, "bad timeline request");
@@ -886,7 +887,7 @@ VP_API int vp_dbg_gemm_timeline(int32_t device, int32_t dtype, int32_t epi, int3
     float* dB;
     unsigned long long* dS;
     int rc;
-    const size_t wrows = pad128(N), nst = (size_t)max_wg * 32 * 3;
+    const size_t wrows = pad128(N), nst = (size_t)max_wg * 32 * 8;
     if ((rc = dalloc(c, &dA, (size_t)M * K)) || (rc = dalloc(c, &dW, wrows * K)) || (rc = dalloc(c, &dB, wrows)) ||
         (rc = dalloc(c, &dO, (size_t)M * N)) || (rc = dalloc(c, &dS, nst)) || (rc = dalloc(c, &c->zero, (size_t)256)))
         return dbg_finish(c, rc);

@@ -179,7 +179,8 @@ VP_API int vp_dbg_crop_prep(int32_t device_id, const uint8_t* frame, int32_t fh,
                             int32_t n, uint8_t* out);
 /* average milliseconds of `iters` launches of one GEMM tile configuration on random device operands */
 /* tools/gemm_timeline.py: per-tile phase stamps (shader cycles) of one persistent qkv / fc1 launch:
- * stamps[max_wg][32][3] = (main loop start, main loop end, epilogue end) of wave 0 of every workgroup. */
+ * stamps[max_wg][32][8] = (main loop start, main loop end, epilogue end, 5 stamps inside k-step 5) of wave 0 of every
+ * workgroup. */
 VP_API int vp_dbg_gemm_timeline(int32_t device, int32_t dtype, int32_t epi, int32_t M, int32_t N, int32_t K, uint64_t* stamps,
                                 int32_t max_wg);
 VP_API int vp_dbg_gemm_bench(int32_t device_id, int32_t dtype, int32_t epi, int32_t variant, int32_t group_m,
