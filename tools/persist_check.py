@@ -25,7 +25,7 @@ if len(sys.argv) > 1 and sys.argv[1] == 'child':
     sys.exit(0)
 
 ok = True
-for variant, batch in (('b', 64), ('b', 256), ('s', 128), ('l', 96)):
+for variant, batch in (('b', 64), ('b', 256), ('s', 128), ('l', 96), ('b', 57), ('b', 100), ('h', 43)):
     hashes = {}
     for flag in ('0', '1'):
         env = dict(os.environ, VP_PERSIST=flag)
