@@ -41,8 +41,8 @@ enum {
     VP_ERR_SHAPE = 5           /* state-dict tensor has the wrong size      */
 };
 
-/* arithmetic type of the GEMM/attention operands (accumulation is always fp32,
- * residual stream / LayerNorm / softmax statistics / heatmaps / decode are fp32) */
+/* arithmetic type of the GEMM/attention operands (accumulation is always fp32; LayerNorm / softmax statistics,
+ * heatmaps and the decode are fp32; the residual stream is held as a hi + lo pair of 16-bit planes, >= 22 bits) */
 enum { VP_DTYPE_F16 = 0, VP_DTYPE_BF16 = 1 };
 
 /* layout of the crop batch handed to vp_infer* */
@@ -77,7 +77,7 @@ typedef struct vp_tensor_desc {
 } vp_tensor_desc;
 
 /* Per-kernel-family timing collected with HIP events on the handle's stream. */
-#define VP_PROF_GEMM_PROJ 0  /* proj/fc2 GEMM  (bias + residual -> fp32)  -- dominant kernel */
+#define VP_PROF_GEMM_PROJ 0  /* proj/fc2 GEMM  (bias + residual + LayerNorm statistics)  -- dominant kernel */
 #define VP_PROF_GEMM_FC1 1   /* fc1 GEMM (bias + GELU)                     */
 #define VP_PROF_GEMM_QKV 2   /* qkv GEMM (bias)                            */
 #define VP_PROF_GEMM_PATCH 3 /* patch-embed GEMM (bias + pos)              */

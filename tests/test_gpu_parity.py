@@ -331,3 +331,14 @@ def test_fused_layernorm_matches_standalone_layernorm(monkeypatch):
         print(f'common-mode offset, fuse_ln={flag}: max|err| {e.max():.3e} rms {np.sqrt((e ** 2).mean()):.3e}')
         assert e.max() < 3 * HM_MAX_ERR['fp16']
         eng.close()
+
+
+def test_plain_c_caller_runs(tmp_path):
+    """examples/c_api_demo.c (gcc, C99, nothing but the header) drives create / load_weights / infer / destroy."""
+    import subprocess
+    from test_host_logic import _build_c_demo
+    exe = _build_c_demo(tmp_path)
+    res = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr
+    lines = [l for l in res.stdout.splitlines() if l.startswith('crop 0 joint')]
+    assert len(lines) == 3 and all('conf' in l for l in lines)

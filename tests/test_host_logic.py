@@ -186,3 +186,29 @@ def test_product_never_imports_the_oracle():
             if f.endswith(('.py', '.hip', '.h')):
                 src = open(os.path.join(dirpath, f), errors='ignore').read()
                 assert not re.search(r'^\s*(from|import)\s+oracle\b', src, re.M), f'{f} imports the oracle'
+
+
+def _build_c_demo(tmp_path):
+    import shutil
+    import subprocess
+    if shutil.which('gcc') is None or not os.path.exists(capi.LIB_PATH):
+        pytest.skip('gcc or the built library is missing')
+    exe = str(tmp_path / 'c_api_demo')
+    libdir = os.path.dirname(capi.LIB_PATH)
+    cmd = ['gcc', '-std=c99', '-Wall', '-Werror', '-I' + os.path.join(ROOT, 'include'), os.path.join(ROOT, 'examples', 'c_api_demo.c'),
+           '-o', exe, '-L' + libdir, '-lvitpose_hip', '-Wl,-rpath,' + libdir, '-lm']
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr
+    return exe
+
+
+def test_c_abi_is_plain_c_and_fails_loudly_without_a_gpu(tmp_path):
+    """The header is valid C99 and a plain-C caller links against the library; on a box without a HIP device the
+    first entry point returns VP_ERR_HIP with a message (no CPU fallback)."""
+    import subprocess
+    import torch
+    exe = _build_c_demo(tmp_path)
+    if torch.cuda.is_available():
+        pytest.skip('GPU present: covered by the gpu-marked run of the same program')
+    res = subprocess.run([exe], capture_output=True, text=True)
+    assert res.returncode == 2 and 'no CPU fallback' in res.stderr
