@@ -14,7 +14,8 @@ namespace vp {
 // 16-byte pieces), its output 12 consecutive rows of the patch matrix (18 KiB contiguous); the
 // transposition in between goes through LDS, so that both HBM sides are fully coalesced (the
 // thread-per-output-chunk version fetched 2.1x the algorithmic bytes: 64-byte pieces of 128-byte lines).
-template <class Ty, int FMT>
+// FLIP: the crop is mirrored left-right on the fly (flip-test, topdown_heatmap_simple_head.py:195-218).
+template <class Ty, int FMT, bool FLIP>
 __global__ __launch_bounds__(256) void im2col_kernel(const void* __restrict__ in, uint16_t* __restrict__ out, int B) {
     constexpr int XS = 208;                                  // LDS row: x = -2 .. 205 (index x + 2)
     __shared__ __attribute__((aligned(16))) uint16_t tile[3 * 16 * XS];
@@ -28,9 +29,15 @@ __global__ __launch_bounds__(256) void im2col_kernel(const void* __restrict__ in
             const int y = ytop + ky;
             f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
             if ((unsigned)y < 256u) v = *(const f32x4*)((const float*)in + (((size_t)b * 3 + c) * 256 + y) * 192 + x4 * 4);
-            uint32_t* dst = (uint32_t*)(tile + (c * 16 + ky) * XS + x4 * 4 + 2);
-            dst[0] = pack2<Ty>(v[0], v[1]);
-            dst[1] = pack2<Ty>(v[2], v[3]);
+            if (FLIP) {   // pixel x of the source row lands at x' = 191 - x
+                uint32_t* dst = (uint32_t*)(tile + (c * 16 + ky) * XS + (188 - x4 * 4) + 2);
+                dst[0] = pack2<Ty>(v[3], v[2]);
+                dst[1] = pack2<Ty>(v[1], v[0]);
+            } else {
+                uint32_t* dst = (uint32_t*)(tile + (c * 16 + ky) * XS + x4 * 4 + 2);
+                dst[0] = pack2<Ty>(v[0], v[1]);
+                dst[1] = pack2<Ty>(v[2], v[3]);
+            }
         }
     } else {
         // 16 rows x 576 bytes (192 px x RGB) as 36 16-byte pieces per row
@@ -48,7 +55,7 @@ __global__ __launch_bounds__(256) void im2col_kernel(const void* __restrict__ in
                 const double stdv = c == 0 ? 0.229 : (c == 1 ? 0.224 : 0.225);
                 const uint8_t u = (uint8_t)(raw[e >> 2] >> ((e & 3) * 8));
                 const float f = inside ? (float)(((double)u / 255.0 - mean) / stdv) : 0.f;
-                tile[(c * 16 + ky) * XS + x + 2] = to_bits<Ty>(f);
+                tile[(c * 16 + ky) * XS + (FLIP ? 191 - x : x) + 2] = to_bits<Ty>(f);
             }
         }
     }
@@ -64,10 +71,14 @@ __global__ __launch_bounds__(256) void im2col_kernel(const void* __restrict__ in
     }
 }
 
-hipError_t im2col_launch(int dtype, const void* crops, int fmt, uint16_t* out, int B, hipStream_t s) {
+hipError_t im2col_launch(int dtype, const void* crops, int fmt, uint16_t* out, int B, hipStream_t s, bool flip) {
     if (B <= 0) return hipSuccess;
     const int grid = B * 16;   // one block per patch row
-#define VP_I2C(TY, F) hipLaunchKernelGGL((im2col_kernel<TY, F>), dim3(grid), dim3(256), 0, s, crops, out, B)
+#define VP_I2C(TY, F)                                                                                              \
+    do {                                                                                                           \
+        if (flip) hipLaunchKernelGGL((im2col_kernel<TY, F, true>), dim3(grid), dim3(256), 0, s, crops, out, B);    \
+        else hipLaunchKernelGGL((im2col_kernel<TY, F, false>), dim3(grid), dim3(256), 0, s, crops, out, B);        \
+    } while (0)
     if (fmt == VP_INPUT_F32_NCHW) {
         if (dtype == DT_F16) VP_I2C(F16, VP_INPUT_F32_NCHW); else VP_I2C(BF16, VP_INPUT_F32_NCHW);
     } else if (fmt == VP_INPUT_U8_NHWC) {
@@ -76,6 +87,34 @@ hipError_t im2col_launch(int dtype, const void* crops, int fmt, uint16_t* out, i
         return hipErrorInvalidValue;
     }
 #undef VP_I2C
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------- flip-test merge
+// hm[n][k][y][x] = 0.5 (hm[n][k][y][x] + back[n][k][y][x]),  back = flip_back(hm_flipped) (post_transforms.py:110-147:
+// channels swapped by the mirror pairs, then reversed in x), optionally shifted right by one pixel
+// (topdown_heatmap_simple_head.py:213-215, `shift_heatmap`); the average is what the flip-test consumer takes.
+__global__ __launch_bounds__(256) void flip_merge_kernel(float* __restrict__ hm, const float* __restrict__ hm_flipped,
+                                                         const int32_t* __restrict__ partner, int K, int shift, size_t total) {
+    for (size_t id = (size_t)blockIdx.x * 256 + threadIdx.x; id < total; id += (size_t)gridDim.x * 256) {
+        const int x = (int)(id % 48);
+        const size_t row = id / 48;                    // (n*K + k)*64 + y
+        const int y = (int)(row & 63);
+        const size_t nk = row >> 6;
+        const int k = (int)(nk % K);
+        const size_t n = nk / K;
+        int xs = x;                                    // column of the flipped-back map before the shift
+        if (shift && x > 0) xs = x - 1;
+        const float b = hm_flipped[((n * K + partner[k]) * 64 + y) * 48 + (47 - xs)];
+        hm[id] = 0.5f * (hm[id] + b);
+    }
+}
+
+hipError_t flip_merge_launch(float* hm, const float* hm_flipped, const int32_t* partner, int N, int K, int shift, hipStream_t s) {
+    const size_t total = (size_t)N * K * 3072;
+    int grid = (int)((total + 255) / 256);
+    if (grid > 16384) grid = 16384;
+    if (total) hipLaunchKernelGGL(flip_merge_kernel, dim3(grid), dim3(256), 0, s, hm, hm_flipped, partner, K, shift, total);
     return hipGetLastError();
 }
 

@@ -81,7 +81,9 @@ hipError_t attention_launch(int dtype, const uint16_t* qkv, uint16_t* out, int B
 hipError_t layernorm_launch(int dtype, const float* x, const float* gamma, const float* beta,
                             uint16_t* out16, float* out32, int M, int D, hipStream_t s, size_t plane = 0);
 // crops -> im2col patch matrix [B*192, 768] 16-bit (k = c*256 + ky*16 + kx, zero border of 2 px)
-hipError_t im2col_launch(int dtype, const void* crops, int input_format, uint16_t* out, int B, hipStream_t s);
+hipError_t im2col_launch(int dtype, const void* crops, int input_format, uint16_t* out, int B, hipStream_t s, bool flip = false);
+// flip-test: hm = 0.5 (hm + flip_back(hm_flipped)); partner[k] = mirror joint of k (k itself if unpaired)
+hipError_t flip_merge_launch(float* hm, const float* hm_flipped, const int32_t* partner, int N, int K, int shift, hipStream_t s);
 
 // frame u8 [FH,FW,3] + params int32 [n,8] (x0,y0,cw,ch,left,top,pw,ph) -> crops u8 [n,256,192,3]
 hipError_t crop_resize_launch(const uint8_t* frame, int FH, int FW, const int32_t* params, uint8_t* out, int n, hipStream_t s);

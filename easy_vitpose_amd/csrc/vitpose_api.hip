@@ -79,6 +79,8 @@ struct vp_ctx {
     float* x = nullptr;
     uint16_t *y = nullptr, *qkv = nullptr, *hid = nullptr, *d1 = nullptr, *d2 = nullptr;
     float *hm = nullptr, *kp = nullptr, *tok = nullptr;
+    float* hm_keep = nullptr;         // flip-test: heatmaps of the un-flipped crops while the flipped pass runs
+    int32_t* partner = nullptr;       // flip-test: mirror joint per joint
     bool persist_gemm = true;         // qkv / fc1 as persistent workgroups at large batch (VP_PERSIST=0: one tile per workgroup)
     int order_mask = 8;               // tile walk last-to-first per GEMM: bit0 qkv, bit1 proj, bit2 fc1, bit3 fc2 (VP_ORDER)
     bool blocked_hid = true;          // mlp hidden activations in the 64x64-blocked layout (VP_BLOCKED_HID=0: row-major)
@@ -368,10 +370,10 @@ int gemm(vp_ctx* c, int fam, int epi, const uint16_t* A, const uint16_t* W, cons
 }
 
 // forward of one chunk (n <= max_batch) with device-resident crops; heatmaps land in c->hm
-int forward_chunk(vp_ctx* c, const void* d_crops, int fmt, int n, bool want_tokens) {
+int forward_chunk(vp_ctx* c, const void* d_crops, int fmt, int n, bool want_tokens, bool flip = false) {
     const int D = c->D, M = n * 192;
     const double in_b = (fmt == VP_INPUT_F32_NCHW ? 4.0 : 1.0) * n * 3.0 * 256 * 192;
-    LAUNCH(c, VP_PROF_IM2COL, 0.0, in_b + 2.0 * M * 768, vp::im2col_launch(c->dtype, d_crops, fmt, c->hid, n, c->stream));
+    LAUNCH(c, VP_PROF_IM2COL, 0.0, in_b + 2.0 * M * 768, vp::im2col_launch(c->dtype, d_crops, fmt, c->hid, n, c->stream, flip));
     int rc;
     size_t plane = 0;   // != 0: the residual stream c->x is held as two 16-bit planes (fused-LayerNorm path)
     if (c->fuse_ln) {
@@ -596,6 +598,43 @@ int vp_infer(vp_handle c, const void* crops, int32_t fmt, int32_t n, const int32
         if ((rc = forward_chunk(c, c->in_stage, fmt, nb, false))) return rc;
         if ((rc = decode_chunk(c, org_wh ? c->wh_stage : nullptr, c->kp, nb))) return rc;
         HIPCHK(c, hipMemcpyAsync(out + (size_t)off * c->Kp * 3, c->kp, (size_t)nb * c->Kp * 12, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    return VP_OK;
+}
+
+int vp_infer_flip(vp_handle c, const void* crops, int32_t fmt, int32_t n, const int32_t* org_wh, const int32_t* flip_pairs,
+                  int32_t n_pairs, int32_t shift_heatmap, float* out, float* heatmaps) {
+    int rc = check_ready(c, fmt, n, crops, out ? (const void*)out : (const void*)heatmaps);
+    if (rc) return rc;
+    if (n_pairs < 0 || (n_pairs > 0 && !flip_pairs)) return fail(c, VP_ERR_INVALID, "bad flip_pairs");
+    std::vector<int32_t> partner(c->Kp);
+    for (int k = 0; k < c->Kp; ++k) partner[k] = k;
+    for (int i = 0; i < n_pairs; ++i) {
+        const int a = flip_pairs[2 * i], b = flip_pairs[2 * i + 1];
+        if (a < 0 || b < 0 || a >= c->Kp || b >= c->Kp) return fail(c, VP_ERR_INVALID, "flip pair index out of range");
+        partner[a] = b;
+        partner[b] = a;
+    }
+    const size_t hm_elems = (size_t)c->maxb * c->Kp * 3072;
+    if (!c->hm_keep && (rc = dalloc(c, &c->hm_keep, hm_elems))) return rc;
+    if (!c->partner && (rc = dalloc(c, &c->partner, (size_t)c->Kp))) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->partner, partner.data(), (size_t)c->Kp * 4, hipMemcpyHostToDevice, c->stream));
+    for (int off = 0; off < n; off += c->maxb) {
+        const int nb = (n - off < c->maxb) ? n - off : c->maxb;
+        const char* src = (const char*)crops + (size_t)off * crop_bytes(fmt);
+        HIPCHK(c, hipMemcpyAsync(c->in_stage, src, (size_t)nb * crop_bytes(fmt), hipMemcpyHostToDevice, c->stream));
+        if (org_wh) HIPCHK(c, hipMemcpyAsync(c->wh_stage, org_wh + 2 * (size_t)off, (size_t)nb * 8, hipMemcpyHostToDevice, c->stream));
+        if ((rc = forward_chunk(c, c->in_stage, fmt, nb, false, false))) return rc;
+        HIPCHK(c, hipMemcpyAsync(c->hm_keep, c->hm, (size_t)nb * c->Kp * 3072 * 4, hipMemcpyDeviceToDevice, c->stream));
+        if ((rc = forward_chunk(c, c->in_stage, fmt, nb, false, true))) return rc;         // mirrored crops -> c->hm
+        HIPCHK(c, vp::flip_merge_launch(c->hm_keep, c->hm, c->partner, nb, c->Kp, shift_heatmap ? 1 : 0, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->hm, c->hm_keep, (size_t)nb * c->Kp * 3072 * 4, hipMemcpyDeviceToDevice, c->stream));
+        if (heatmaps) HIPCHK(c, hipMemcpyAsync(heatmaps + (size_t)off * c->Kp * 3072, c->hm, (size_t)nb * c->Kp * 3072 * 4, hipMemcpyDeviceToHost, c->stream));
+        if (out) {
+            if ((rc = decode_chunk(c, org_wh ? c->wh_stage : nullptr, c->kp, nb))) return rc;
+            HIPCHK(c, hipMemcpyAsync(out + (size_t)off * c->Kp * 3, c->kp, (size_t)nb * c->Kp * 12, hipMemcpyDeviceToHost, c->stream));
+        }
         HIPCHK(c, hipStreamSynchronize(c->stream));
     }
     return VP_OK;

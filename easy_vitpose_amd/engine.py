@@ -96,6 +96,23 @@ class VitPoseHip:
         capi.check(self.lib.vp_infer_device(self._h, d_crops.data_ptr(), fmt, n, whp, d_out.data_ptr(), int(sync)), self._h)
         return d_out
 
+    def infer_flip(self, crops: np.ndarray, flip_pairs, org_wh=None, shift_heatmap: bool = False, return_heatmaps: bool = False):
+        """Flip-test inference (reference head `inference_model(x, flip_pairs)` + `flip_back`, topdown_heatmap_simple_head.py:
+        195-218, post_transforms.py:110-147): average of the heatmaps of the crops and of their flipped-back mirror images,
+        then the usual decode.  `flip_pairs`: the dataset's mirror joint pairs [[l, r], ...] (the reference ships none)."""
+        crops = np.ascontiguousarray(crops)
+        n = crops.shape[0]
+        pairs = np.ascontiguousarray(np.asarray(flip_pairs, dtype=np.int32).reshape(-1, 2))
+        wh = None if org_wh is None else np.ascontiguousarray(org_wh, dtype=np.int32).reshape(n, 2)
+        out = np.empty((n, self.K, 3), dtype=np.float32)
+        hm = np.empty((n, self.K, HM_H, HM_W), dtype=np.float32) if return_heatmaps else None
+        if n:
+            capi.check(self.lib.vp_infer_flip(self._h, crops.ctypes.data, self._fmt(crops), n,
+                                              None if wh is None else wh.ctypes.data, pairs.ctypes.data if len(pairs) else None,
+                                              len(pairs), int(bool(shift_heatmap)), out.ctypes.data,
+                                              None if hm is None else hm.ctypes.data), self._h)
+        return (out, hm) if return_heatmaps else out
+
     def infer_frame(self, frame: np.ndarray, params: np.ndarray) -> np.ndarray:
         """Whole frame + crop geometry (cropprep.crop_params) -> [n, K, 3] in padded-crop pixels (vp_infer_frame)."""
         frame = np.ascontiguousarray(frame)

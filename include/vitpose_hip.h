@@ -130,6 +130,15 @@ VP_API int vp_infer_device(vp_handle h, const void* d_crops, int32_t input_forma
 VP_API int vp_infer_frame(vp_handle h, const uint8_t* frame, int32_t fh, int32_t fw, const int32_t* crop_params,
                           int32_t n, float* out);
 
+/* Flip-test inference (the optional accuracy mode of the reference head, topdown_heatmap_simple_head.py:195-218 with
+ * flip_back of vit_utils/post_processing/post_transforms.py:110-147; `flip_test=True, shift_heatmap=False` in
+ * configs/ViTPose_common.py:91-93): the model runs on the crops and on their left-right mirror, the mirrored heatmaps are
+ * flipped back (joint pairs swapped, x reversed, optionally shifted one pixel right) and averaged with the first ones, the
+ * average is decoded.  flip_pairs = n_pairs x 2 joint indices (the dataset's mirror pairs; the reference ships none).
+ * out [n,K,3] and / or heatmaps [n,K,64,48] (either may be NULL, not both). */
+VP_API int vp_infer_flip(vp_handle h, const void* crops, int32_t input_format, int32_t n, const int32_t* org_wh,
+                         const int32_t* flip_pairs, int32_t n_pairs, int32_t shift_heatmap, float* out, float* heatmaps);
+
 /* Parity/debug taps.  Heatmaps = ViTPose.forward output, float32 [N, K, 64, 48]. */
 VP_API int vp_infer_heatmaps(vp_handle h, const void* crops, int32_t input_format, int32_t n, float* heatmaps);
 /* Backbone output after last_norm (vit.py:387), float32 [N, 192, D]. */

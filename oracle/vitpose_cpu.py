@@ -262,3 +262,25 @@ def inference_torch(sd, depth: int, num_heads: int, img_u8: np.ndarray) -> np.nd
 
 def to_torch_state_dict(sd_np) -> "dict[str, torch.Tensor]":
     return {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in sd_np.items()}
+
+
+def flip_back(output_flipped: np.ndarray, flip_pairs) -> np.ndarray:
+    """``flip_back(..., target_type='GaussianHeatmap')`` (vit_utils/post_processing/post_transforms.py:110-147):
+    swap the mirrored joint channels, then reverse the width axis."""
+    assert output_flipped.ndim == 4
+    back = output_flipped.copy()
+    for left, right in flip_pairs:
+        back[:, left] = output_flipped[:, right]
+        back[:, right] = output_flipped[:, left]
+    return back[..., ::-1]
+
+
+def flip_test_heatmaps(sd, x: np.ndarray, depth: int, num_heads: int, flip_pairs, shift_heatmap: bool = False) -> np.ndarray:
+    """Flip-test: heatmaps of the crops averaged with the flipped-back heatmaps of their mirror images
+    (head ``inference_model``, topdown_heatmap_simple_head.py:195-218 incl. the optional one-pixel shift :213-215;
+    the 0.5 (a + b) average is what the flip-test consumer computes)."""
+    a = model_forward(sd, x, depth, num_heads)
+    b = flip_back(model_forward(sd, np.ascontiguousarray(x[..., ::-1]), depth, num_heads), flip_pairs).copy()
+    if shift_heatmap:
+        b[:, :, :, 1:] = b.copy()[:, :, :, :-1]
+    return (0.5 * (a + b)).astype(np.float32)

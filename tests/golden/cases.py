@@ -78,3 +78,8 @@ def frame_case():
                       [575.5, 20.0, 639.0, 300.0, 0.55],
                       [10.0, 10.0, 50.0, 50.0, 0.20]], dtype=np.float64)
     return frame, boxes
+
+
+def coco_flip_pairs():
+    """Mirror joint pairs of the COCO-17 layout (left/right eye, ear, shoulder, elbow, wrist, hip, knee, ankle)."""
+    return [[1, 2], [3, 4], [5, 6], [7, 8], [9, 10], [11, 12], [13, 14], [15, 16]]

@@ -140,6 +140,14 @@ def main():
                      int((out[top:top + h, left:left + w] != img).sum())])
     np.savez_compressed(os.path.join(HERE, 'pad_image.npz'), rows=np.asarray(rows, dtype=np.int64))
 
+    # (1b) the reference's flip_back on seeded heatmaps (mirror pairs of COCO-17: 1-2, 3-4, ..., 15-16)
+    from easy_ViTPose.vit_utils.post_processing.post_transforms import flip_back as ref_flip_back
+    from cases import coco_flip_pairs
+    fh = np.random.default_rng(33).standard_normal((2, 17, 64, 48)).astype(np.float32)
+    fb = ref_flip_back(fh.copy(), coco_flip_pairs(), target_type='GaussianHeatmap')
+    print(f'flip_back: oracle-vs-reference max|d| = {np.abs(O.flip_back(fh, coco_flip_pairs()) - fb).max():.3e}')
+    np.savez_compressed(os.path.join(HERE, 'flip_back.npz'), seed=33, expected=np.ascontiguousarray(fb))
+
     # (2) the reference's VitInference.inference(img) end to end on a synthetic frame: a fake detector object with
     #     the ultralytics result interface feeds the reference's own box loop (inference.py:221-281)
     frame, boxes = frame_case()

@@ -333,6 +333,29 @@ def test_fused_layernorm_matches_standalone_layernorm(monkeypatch):
         eng.close()
 
 
+@pytest.mark.parametrize('shift', [False, True])
+def test_flip_test_matches_oracle(shift):
+    """Flip-test path (f-3): heatmaps of the crops and of their mirror images, flipped back (oracle pinned to the
+    reference's flip_back golden), averaged, decoded -- against the oracle doing the same with the fp32 model."""
+    from cases import coco_flip_pairs
+    shp, sd, sdt = weights('s', 'coco')
+    crops = synthetic_crops(3, 13, 'blobs')
+    x = np.concatenate([O.pre_img(c)[0] for c in crops])
+    ref_hm = O.flip_test_heatmaps(sdt, x, shp.depth, shp.num_heads, coco_flip_pairs(), shift_heatmap=shift)
+    eng = VitPoseHip(shp, sd, dtype='fp16', max_batch=2)            # 3 crops -> chunks of 2 + 1
+    kp, hm = eng.infer_flip(crops, coco_flip_pairs(), shift_heatmap=shift, return_heatmaps=True)
+    err = np.abs(hm - ref_hm)
+    print(f'flip test (shift={shift}): heatmap max|err| {err.max():.3e} rms {np.sqrt((err ** 2).mean()):.3e}')
+    assert err.max() < HM_MAX_ERR['fp16'] and np.sqrt((err ** 2).mean()) < HM_RMS_ERR['fp16']
+    assert np.array_equal(kp, decode_heatmaps(hm))                   # the decode runs on the averaged maps
+    assert np.abs(kp[..., 2] - O.decode_per_crop(ref_hm)[..., 2]).max() < CONF_TOL
+    # a mirror-symmetric check that needs no oracle: flipping the input AND swapping the pairs reproduces the same average
+    kp2, hm2 = eng.infer_flip(np.ascontiguousarray(crops[:, :, ::-1]), coco_flip_pairs(), return_heatmaps=True)
+    if not shift:
+        assert np.abs(O.flip_back(hm2, coco_flip_pairs()) - hm).max() < 2e-3
+    eng.close()
+
+
 def test_plain_c_caller_runs(tmp_path):
     """examples/c_api_demo.c (gcc, C99, nothing but the header) drives create / load_weights / infer / destroy."""
     import subprocess
