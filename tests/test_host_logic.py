@@ -212,3 +212,18 @@ def test_c_abi_is_plain_c_and_fails_loudly_without_a_gpu(tmp_path):
         pytest.skip('GPU present: covered by the gpu-marked run of the same program')
     res = subprocess.run([exe], capture_output=True, text=True)
     assert res.returncode == 2 and 'no CPU fallback' in res.stderr
+
+
+def test_json_wire_format_like_reference_cli(tmp_path):
+    """`--save-json` layout of the reference CLI (inference.py:136-141): {"keypoints": [per-frame {id: [[y,x,score]..]}],
+    "skeleton": {index: name}} with ndarrays serialised as nested lists."""
+    import json
+    from easy_vitpose_amd.jsonio import COCO17_JOINTS, frames_to_json, save_json
+    kp = np.arange(17 * 3, dtype=np.float32).reshape(17, 3)
+    frames = [{0: kp, 1: kp + 1}, {}, {np.int64(7): kp}]
+    d = json.loads(frames_to_json(frames, COCO17_JOINTS))
+    assert sorted(d) == ['keypoints', 'skeleton'] and len(d['keypoints']) == 3 and d['keypoints'][1] == {}
+    assert d['keypoints'][0]['1'][2] == [7.0, 8.0, 9.0] and list(d['keypoints'][2]) == ['7']
+    assert d['skeleton']['0'] == 'nose' and len(d['skeleton']) == 17
+    save_json(str(tmp_path / 'o.json'), frames)
+    assert json.load(open(tmp_path / 'o.json'))['skeleton'] == {}
