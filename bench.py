@@ -96,6 +96,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--dtype', default='fp16', choices=['fp16', 'bf16'])
     ap.add_argument('--batch', type=int, default=256)
+    ap.add_argument('--max-batch', type=int, default=0, help='workspace batch of the handle (< --batch: the batch is processed in chunks)')
     ap.add_argument('--variant', default='b')
     ap.add_argument('--dataset', default='coco')
     ap.add_argument('--input', default='f32', choices=['f32', 'u8'])
@@ -125,7 +126,7 @@ def main():
 
     shp = model_shape(args.variant, args.dataset)
     B, K = args.batch, shp.num_keypoints
-    eng = VitPoseHip(shp, synthetic_state_dict(shp, 0), dtype=args.dtype, device_id=local_rank, max_batch=B)
+    eng = VitPoseHip(shp, synthetic_state_dict(shp, 0), dtype=args.dtype, device_id=local_rank, max_batch=args.max_batch or B)
     crops_u8 = synthetic_crops(B, seed=rank, kind='noise')
     if args.input == 'u8':
         d_crops = torch.from_numpy(crops_u8).to(dev)

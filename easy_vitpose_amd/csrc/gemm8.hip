@@ -1,0 +1,517 @@
+// 8-phase MFMA GEMM for the large-batch encoder GEMMs:  C[m][n] = sum_k A[m][k] * W[n][k]
+//
+// One 512-thread workgroup per CU computes 256(m) x BN(n) tiles (BN = 256 or 192) in K-tiles of 64.  The structure
+// follows the "8-phase, counted vmcnt" schedule of the CDNA4 guide, rebuilt for this model's shapes:
+//
+//  * operand halves.  A K-tile in LDS = four independently staged slots: X0, X1 (activation rows 0-127 / 128-255 of the
+//    tile) and W0, W1 (weight rows: 128 + (BN - 128)).  Two K-tiles are resident (ring of 2 x 4 slots, 128 / 112 KiB).
+//    Every wave owns a 128(m) x BN/4(n) output block made of 64 rows from EACH X half and BN/8 (BN = 256) rows from each W
+//    half, so its accumulators split into four quadrants q(hm, hn) = X-half hm x W-half hn, and a quadrant needs exactly
+//    one X slot and one W slot.
+//  * 4 phases per K-tile, 8 per loop iteration (two K-tiles, compile-time buffer index):
+//        P1: read W0 + X0 fragments | DMA X1(t+1) | barrier | MFMA q00 | barrier
+//        P2: read W1 fragments      | DMA W0(t+2) | barrier | MFMA q01 | barrier
+//        P3: read X1 fragments      | DMA X0(t+2) | barrier | MFMA q11 | barrier
+//        P4: (W0 kept in registers) | DMA W1(t+2) | vmcnt | barrier | MFMA q10 | barrier
+//    One slot is restaged per phase (global_load_lds, 16 B per lane); the only vmcnt wait of a K-tile sits in P4 and is
+//    COUNTED (the three youngest slots stay in flight across it), so HBM/L2 latency is covered by 3-6 phases of MFMAs.
+//  * two wave groups (waves 0-3 / 4-7 = the two waves of every SIMD) run the same stream ONE BARRIER APART: while
+//    one wave of a SIMD streams its 16 MFMAs, its SIMD partner reads fragments and issues the DMA of its phase.
+//  * ordering rules the schedule is built on (MI355X_MICROARCH.md, "Two waves per SIMD", item 7):
+//      RAW: a slot is read one phase AFTER the phase whose vmcnt retired it (P4(t) retires K-tile t+1, read from P1(t+1));
+//      WAR: a slot is restaged >= 2 phases after its last ds_read (X0: P1 -> P3, W1: P2 -> P4, X1: P3 -> P1 of the next
+//           K-tile), or 1 phase after when those reads were retired by an lgkmcnt BEFORE the reading phase's first
+//           barrier (W0: read first in P1, `s_waitcnt lgkmcnt(8)` before the barrier, restaged in P2).
+//  * the LDS image of a slot is lane-linear (global_load_lds writes wave base + lane * 16): the XOR swizzle of the
+//    16-byte k-slots is applied to the per-lane SOURCE address and again on the ds_read_b128 fragment reads.
+//  * persistent workgroups: the ring runs on across tile boundaries (the next tile's first two K-tiles stream in during
+//    the last phases and the epilogue of the current one).
+//  * W rows are PERMUTED on their way into LDS (free: the source address of a DMA lane is arbitrary) so that the 4 * TI
+//    accumulator values a lane holds for one output row are CONSECUTIVE columns: the 16-bit epilogues (qkv, fc1) store
+//    straight from registers as 16-byte pieces that complete 128-byte lines -- no LDS round trip, no epilogue barrier.
+//  * the residual epilogue (attn.proj / mlp.fc2: + bias + residual planes, two-plane output, LayerNorm row statistics)
+//    stages the tile through LDS exactly like gemm.hip's producer epilogue (bit-identical statistics order).
+//
+// Accumulation order per output element is the same as in gemm.hip (k ascending in steps of 32), so results are
+// bit-identical to the 2-phase kernels: that identity is the race screen (tools/gemm8_check.py, tests).
+#include <type_traits>
+#include <utility>
+
+#include "common.h"
+#include "kernels.h"
+
+namespace vp {
+
+namespace {
+
+template <int BN_> struct G8 {
+    static constexpr int BM = 256, BN = BN_, NT = 512;
+    static constexpr int WH1 = BN - 128;            // rows of W half 1 (128 or 64)
+    static constexpr int NF1 = WH1 / 64;            // n-fragments of a wave from W half 1 (2 or 1)
+    static constexpr int TI = 2 + NF1, TJ = 8;      // fragments per wave: n, m
+    static constexpr int HALF = 128 * 128;          // bytes of a 128-row slot (BK = 64 16-bit values per row)
+    static constexpr int OFF_X0 = 0, OFF_X1 = HALF, OFF_W0 = 2 * HALF, OFF_W1 = 3 * HALF;
+    static constexpr int BUF = 3 * HALF + WH1 * 128;
+    static constexpr int RING = 2 * BUF;
+    static constexpr int NW1 = WH1 / 64;            // DMA instructions per wave for W half 1
+    static constexpr int INFLIGHT = 4 + NW1;        // DMAs of the three youngest slots (W0, X0, W1) at the P4 wait
+    static_assert(BN == 256 || BN == 192, "BN");
+};
+
+template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+template <int N> __device__ __forceinline__ void wait_lgkm() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory"); }
+__device__ __forceinline__ void bar() {
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+__device__ __forceinline__ float gelu8(float x) {   // identical to gemm.hip's gelu_erf
+    const float a = fabsf(x);
+    float q = fmaf(a, 5.204574411e-04f, -7.397505390e-03f);
+    q = fmaf(q, a, 5.256122897e-02f);
+    q = fmaf(q, a, 4.592546873e-01f);
+    q = fmaf(q, a, 1.151091354e+00f);
+    const float e = __builtin_amdgcn_exp2f(-(q * a));
+    return fmaf(-0.5f * a, e, fmaxf(x, 0.f));
+}
+
+__device__ __forceinline__ float row8_sum8(float x) {   // identical to gemm.hip's row8_sum
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xF, 0xF, true));
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x4E, 0xF, 0xF, true));
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x141, 0xF, 0xF, true));
+    return x;
+}
+
+struct TileWalk {   // XCD-contiguous, grouped tile order (same as gemm.hip's persistent kernel)
+    int tiles_m, tiles_n, group_m, base, cnt, j0, nloc;
+    __device__ __forceinline__ void init(const GemmArgs& g, int BM, int BN) {
+        tiles_n = (g.N + BN - 1) / BN;
+        tiles_m = (g.M + BM - 1) / BM;
+        group_m = g.group_m;
+        const int ntiles = tiles_m * tiles_n;
+        const int xcd = blockIdx.x & 7;
+        j0 = blockIdx.x >> 3;
+        nloc = gridDim.x >> 3;
+        const int q = ntiles >> 3, r8 = ntiles & 7;
+        base = (xcd < r8) ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q;
+        cnt = q + (xcd < r8 ? 1 : 0);
+    }
+    __device__ __forceinline__ void origin(int t, int reverse, int BM, int BN, int& m0, int& n0) const {
+        int bid = base + t;
+        if (reverse) bid = tiles_m * tiles_n - 1 - bid;
+        int tm, tn;
+        if (group_m > 1) {
+            const int per_group = group_m * tiles_n;
+            const int grp = bid / per_group, first_m = grp * group_m;
+            const int gsz = min(tiles_m - first_m, group_m);
+            const int r = bid - grp * per_group;
+            tm = first_m + r % gsz;
+            tn = r / gsz;
+        } else {
+            tm = bid / tiles_n;
+            tn = bid - tm * tiles_n;
+        }
+        m0 = tm * BM;
+        n0 = tn * BN;
+    }
+};
+
+}  // namespace
+
+// EPI: EPI_BIAS / EPI_BIAS_GELU (16-bit output straight from registers, optional LayerNorm-consumer fold, optional
+// 64x64-blocked output) or EPI_BIAS_RESID_LN (two-plane residual stream + row statistics, staged through LDS).
+template <class T, int EPI, class C>
+__global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs g) {
+    constexpr bool RESID = (EPI == EPI_BIAS_RESID_LN);
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;          // wave group (stagger) / column block
+    const int K = g.K, nk = K >> 6;
+    TileWalk tw;
+    tw.init(g, C::BM, C::BN);
+    if (tw.j0 >= tw.cnt) return;
+
+    // ---- staging addresses: wave-uniform bases + one per-lane byte offset per operand ----
+    // piece p (8 rows x 128 B = one DMA wave-instruction) of a slot = LDS rows 8p .. 8p+7; wave w issues p = w (and w + 8)
+    const int rip = lane >> 3, pslot = lane & 7;
+    const int slog = pslot ^ (((wave & 1) << 2) | (rip >> 1));   // logical k-slot this lane fetches (swizzled image)
+    const uint32_t voff_x = g.a_blocked ? (uint32_t)(rip * 128 + slog * 16) : (uint32_t)(rip * K + slog * 8) * 2u;
+    // W row permutation: LDS row r of half h holds tile column  wc(r) 16 TI + (rho >> 2) 4 TI + f 4 + (rho & 3),
+    // rho = r & 15, f = fragment index of the wave (half 0: (r >> 4) & 1, half 1: 2 + ...), wc(r) = owner wave column
+    const int rho = ((wave & 1) << 3) | rip;
+    const uint32_t voff_w = (uint32_t)(((rho >> 2) * 4 * C::TI + (rho & 3)) * K + slog * 8) * 2u;
+    const int wu0 = (wave >> 2) * 16 * C::TI + ((wave >> 1) & 1) * 4;                       // half 0, piece w   (piece w + 8: + 32 TI)
+    const int wu1 = (C::BN == 256) ? wu0 + 8 : (wave >> 1) * 16 * C::TI + 8;                // half 1, piece w   (BN = 256: piece w + 8: + 32 TI)
+    const size_t xrow_bytes = g.a_blocked ? 128 : (size_t)K * 2;                            // bytes between consecutive rows of a piece
+    const size_t x64 = g.a_blocked ? (size_t)(K >> 6) * 8192 : (size_t)64 * K * 2;          // + 64 rows
+    const size_t xkt = g.a_blocked ? 8192 : 128;                                            // + one K-tile
+    const char* xb = nullptr;   // current issue tile: X rows m0 + 8 w
+    const char* wb = nullptr;   // W rows n0 (column permutation applied by wu0 / wu1 / voff_w)
+    auto set_tile = [&](int m0, int n0) {
+        xb = g.a_blocked ? (const char*)(g.A + ((size_t)(m0 >> 6) * (K >> 6) << 12)) + (size_t)wave * 8 * 128
+                         : (const char*)(g.A + (size_t)(m0 + wave * 8) * K);
+        wb = (const char*)(g.W + (size_t)n0 * K);
+        (void)xrow_bytes;
+    };
+    // DMA of one slot of K-tile kt (of the issue tile) into ring buffer B
+    auto issue = [&](int which, int B, int kt, bool force = false) {
+        char* dst = smem + B * C::BUF + wave * 1024;
+        if ((g.ablate & 1) && !force) return;
+        if (which < 2) {   // X half `which`
+            const char* src = xb + (size_t)(which * 2) * x64 + (size_t)kt * xkt + voff_x;
+            glds16(src, dst + which * C::HALF);
+            glds16(src + x64, dst + which * C::HALF + 8192);
+        } else if (which == 2) {
+            const char* src = wb + ((size_t)wu0 * K + (size_t)kt * 64) * 2 + voff_w;
+            glds16(src, dst + C::OFF_W0);
+            glds16(src + (size_t)32 * C::TI * K * 2, dst + C::OFF_W0 + 8192);
+        } else {
+            const char* src = wb + ((size_t)wu1 * K + (size_t)kt * 64) * 2 + voff_w;
+            glds16(src, dst + C::OFF_W1);
+            if (C::NW1 == 2) glds16(src + (size_t)32 * C::TI * K * 2, dst + C::OFF_W1 + 8192);
+        }
+    };
+
+    // ---- fragment read offsets (bytes inside a slot) ----
+    const int frow = lane & 15, fg = lane >> 4;
+    const int foff = frow * 128 + ((fg ^ ((frow >> 1) & 7)) << 4);
+    const int xoff = wr * 64 * 128 + foff;            // X half h: + j * 2048, kk: ^ 64
+    const int w0off = wc * 32 * 128 + foff;           // W half 0: + phi * 2048
+    const int w1off = wc * 16 * C::NF1 * 128 + foff;  // W half 1
+
+    f32x4 acc[C::TI][8];
+    u32x4 xs[4][2], w0[2][2], w1[C::NF1][2];
+
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int f = 0; f < C::TI; ++f)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[f][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    };
+
+    // one K-tile: ring buffer B holds it; kn1 / kn2 = K-tile indices (relative to the ISSUE tile pointers) of the
+    // K-tiles one and two ahead; sw = switch the issue pointers to the next tile after P1 (the K-tile two ahead, and
+    // from then on everything issued, belongs to the next tile)
+    auto ktile = [&](auto Bc, int kn1, int kn2, bool sw, int nm0, int nn0) {
+        constexpr int B = decltype(Bc)::value;
+        const char* sb = smem + B * C::BUF;
+        // ---------------- P1
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) w0[p][kk] = *(const u32x4*)(sb + C::OFF_W0 + ((w0off + p * 2048) ^ (kk << 6)));
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) xs[j][kk] = *(const u32x4*)(sb + C::OFF_X0 + ((xoff + j * 2048) ^ (kk << 6)));
+        __builtin_amdgcn_sched_barrier(0);
+        issue(1, B ^ 1, kn1);
+        if (sw) set_tile(nm0, nn0);
+        wait_lgkm<8>();   // the four W0 reads (issued first) have returned: slot W0 may be restaged in P2
+        bar();
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int p = 0; p < 2; ++p)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[p][j] = mfma16<T>(w0[p][kk], xs[j][kk], acc[p][j]);
+        __builtin_amdgcn_s_setprio(0);
+        bar();
+        // ---------------- P2
+#pragma unroll
+        for (int p = 0; p < C::NF1; ++p)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) w1[p][kk] = *(const u32x4*)(sb + C::OFF_W1 + ((w1off + p * 2048) ^ (kk << 6)));
+        __builtin_amdgcn_sched_barrier(0);
+        issue(2, B, kn2);
+        bar();
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int p = 0; p < C::NF1; ++p)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[2 + p][j] = mfma16<T>(w1[p][kk], xs[j][kk], acc[2 + p][j]);
+        __builtin_amdgcn_s_setprio(0);
+        bar();
+        // ---------------- P3
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) xs[j][kk] = *(const u32x4*)(sb + C::OFF_X1 + ((xoff + j * 2048) ^ (kk << 6)));
+        __builtin_amdgcn_sched_barrier(0);
+        issue(0, B, kn2);
+        bar();
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int p = 0; p < C::NF1; ++p)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[2 + p][4 + j] = mfma16<T>(w1[p][kk], xs[j][kk], acc[2 + p][4 + j]);
+        __builtin_amdgcn_s_setprio(0);
+        bar();
+        // ---------------- P4
+        issue(3, B, kn2);
+        wait_vm<C::INFLIGHT>();   // everything up to P1's DMA has landed (own share): K-tile t+1 is complete
+        bar();
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int p = 0; p < 2; ++p)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[p][4 + j] = mfma16<T>(w0[p][kk], xs[j][kk], acc[p][4 + j]);
+        __builtin_amdgcn_s_setprio(0);
+        bar();
+    };
+
+    // ---- prologue of the first tile: K-tile 0 complete, W0 / X0 / W1 of K-tile 1 in flight ----
+    int t = tw.j0, m0, n0;
+    tw.origin(t, g.reverse, C::BM, C::BN, m0, n0);
+    set_tile(m0, n0);
+    issue(2, 0, 0, true); issue(0, 0, 0, true); issue(3, 0, 0, true); issue(1, 0, 0, true);
+    issue(2, 1, 1, true); issue(0, 1, 1, true); issue(3, 1, 1, true);
+    wait_vm<C::INFLIGHT>();
+    bar();
+    if (wr) bar();   // stagger: waves 4-7 run one barrier behind waves 0-3
+
+    for (;;) {
+        zero_acc();
+        const bool has_next = t + tw.nloc < tw.cnt;
+        int nm0 = m0, nn0 = n0;   // no next tile: the ring keeps fetching (valid, unused) K-tiles 0 / 1 of this tile
+        if (has_next) tw.origin(t + tw.nloc, g.reverse, C::BM, C::BN, nm0, nn0);
+        for (int kt = 0; kt < nk - 2; kt += 2) {
+            ktile(std::integral_constant<int, 0>{}, kt + 1, kt + 2, false, 0, 0);
+            ktile(std::integral_constant<int, 1>{}, kt + 2, kt + 3, false, 0, 0);
+        }
+        // last two K-tiles: K-tile nk-2 still issues X1 of K-tile nk-1 from this tile, everything after it is the next tile's
+        ktile(std::integral_constant<int, 0>{}, nk - 1, 0, true, nm0, nn0);
+        ktile(std::integral_constant<int, 1>{}, 0, 1, false, 0, 0);
+
+        // ---------------- epilogue of tile (m0, n0) ----------------
+        if constexpr (!RESID) {
+            // lane (fg, frow): rows m0 + (J >> 2) 128 + wr 64 + (J & 3) 16 + frow, columns n0 + wc 16 TI + fg 4 TI + [0, 4 TI).
+            // Every operand of the epilogue is loaded up front (one latency, not one per row group); the LayerNorm-consumer
+            // variant is chosen by ONE wave-uniform branch around the whole block.
+            const int nb = n0 + wc * 16 * C::TI + fg * 4 * C::TI;
+            const int mrow = m0 + wr * 64 + frow;
+            auto epilogue = [&](auto LNc) {
+                constexpr bool LN = decltype(LNc)::value;
+                f32x4 bias4[C::TI], s4[LN ? C::TI : 1];
+                float2 st[LN ? 8 : 1];
+#pragma unroll
+                for (int f = 0; f < C::TI; ++f) bias4[f] = *(const f32x4*)(g.bias + nb + f * 4);
+                if constexpr (LN) {
+#pragma unroll
+                    for (int f = 0; f < C::TI; ++f) s4[f] = *(const f32x4*)(g.ln_s + nb + f * 4);
+#pragma unroll
+                    for (int J = 0; J < 8; ++J) st[J] = *(const float2*)(g.rowstat + 2 * (size_t)(mrow + (J >> 2) * 128 + (J & 3) * 16));
+                }
+                uint16_t* obase = g.out_blocked
+                    ? (uint16_t*)g.out + (((size_t)(mrow >> 6) * (g.ldo >> 6) + (nb >> 6)) << 12) + ((mrow & 63) << 6) + (nb & 63)
+                    : (uint16_t*)g.out + (size_t)mrow * g.ldo + nb;
+                // + 16 rows: blocked 16 * 64 elements (mrow & 63 = wr-independent multiple: rows stay inside one 64-row block
+                // for (J & 3) 16 + frow < 64), + 128 rows: two block rows
+                const size_t step16 = g.out_blocked ? (size_t)16 * 64 : (size_t)16 * g.ldo;
+                const size_t step128 = g.out_blocked ? ((size_t)2 * (g.ldo >> 6) << 12) : (size_t)128 * g.ldo;
+                const bool store = !(g.ablate & 8);
+#pragma unroll
+                for (int J = 0; J < 8; ++J) {
+                    uint32_t o[2 * C::TI];
+#pragma unroll
+                    for (int f = 0; f < C::TI; ++f) {
+                        f32x4 v = acc[f][J];
+                        if constexpr (LN) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) v[r] = (v[r] - st[J].x * s4[f][r]) * st[J].y;
+                        }
+                        v += bias4[f];
+                        if (EPI == EPI_BIAS_GELU) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) v[r] = gelu8(v[r]);
+                        }
+                        o[2 * f] = pack2<T>(v[0], v[1]);
+                        o[2 * f + 1] = pack2<T>(v[2], v[3]);
+                    }
+                    uint16_t* dst = obase + (size_t)(J >> 2) * step128 + (size_t)(J & 3) * step16;
+                    if (store) {
+                        if constexpr (C::TI == 4) {
+                            *(u32x4*)dst = u32x4{o[0], o[1], o[2], o[3]};
+                            *(u32x4*)(dst + 8) = u32x4{o[4], o[5], o[6], o[7]};
+                        } else {   // 12 columns = 24 bytes, 8-byte aligned
+                            *(u32x2*)dst = u32x2{o[0], o[1]};
+                            *(u32x2*)(dst + 4) = u32x2{o[2], o[3]};
+                            *(u32x2*)(dst + 8) = u32x2{o[4], o[5]};
+                        }
+                    }
+                }
+            };
+            if (g.rowstat != nullptr) epilogue(std::true_type{});
+            else epilogue(std::false_type{});
+        } else {
+            // Residual epilogue through LDS (the ring is drained first and restarted afterwards: fc2's 48 K-tiles make
+            // the tile boundary cheap).  Arithmetic and statistics order = gemm.hip's fused-LayerNorm producer.
+            constexpr int ROWBYTES = C::BN * 4 + 16;
+            constexpr int JPP = (C::BN == 256) ? 2 : 4;  // m-fragments (per wave and X half) staged per pass
+            constexpr int CR = 32 * JPP;                 // rows per pass
+            constexpr int NPASS = 256 / CR;
+            constexpr int CPR = C::BN / 8;               // 8-element chunks per row
+            constexpr int NCH = CR * CPR / C::NT;        // chunks per thread per pass
+            constexpr int GR = C::BN / 64;
+            static_assert(NCH * C::NT == CR * CPR, "chunks must split evenly over threads");
+            static_assert(CR * ROWBYTES + C::BM * GR * 8 <= 160 * 1024, "LDS");
+            float* statbuf = (float*)(smem + CR * ROWBYTES);
+            uint16_t* out_hi = (uint16_t*)g.out;
+            uint16_t* out_lo = out_hi + g.plane;
+            const uint16_t* aux_hi = (const uint16_t*)g.aux;
+            const uint16_t* aux_lo = aux_hi + g.plane;
+            const int nl = wc * 16 * C::TI + fg * 4 * C::TI;   // first tile column of this lane
+            f32x4 bias4[C::TI];
+#pragma unroll
+            for (int f = 0; f < C::TI; ++f) bias4[f] = *(const f32x4*)(g.bias + n0 + nl + f * 4);
+            wait_vm<0>();
+            if (!wr) bar();     // undo the stagger: both groups meet here
+            __syncthreads();    // every wave is done with the ring
+            // staged row lr of pass p  <->  tile row (p / (4/JPP)) 128 + (lr / (16 JPP)) 64 + ((p % (4/JPP)) JPP + (lr / 16) % JPP) 16 + lr % 16
+            auto tile_row = [&](int p, int lr) {
+                return (p / (4 / JPP)) * 128 + (lr / (16 * JPP)) * 64 + ((p % (4 / JPP)) * JPP + (lr / 16) % JPP) * 16 + (lr & 15);
+            };
+#pragma unroll
+            for (int p = 0; p < NPASS; ++p) {
+                size_t orow_q[NCH];
+                u32x4 ra[NCH], rb[NCH];
+#pragma unroll
+                for (int q = 0; q < NCH; ++q) {
+                    const int c = tid + q * C::NT;
+                    const int lr = c / CPR, ch = c - lr * CPR;
+                    const int m = m0 + tile_row(p, lr);
+                    orow_q[q] = (size_t)m * g.ldo;
+                    ra[q] = *(const u32x4*)(aux_hi + orow_q[q] + n0 + ch * 8);
+                    rb[q] = *(const u32x4*)(aux_lo + orow_q[q] + n0 + ch * 8);
+                }
+#pragma unroll
+                for (int jj = 0; jj < JPP; ++jj) {
+                    char* lrow = smem + (wr * 16 * JPP + jj * 16 + frow) * ROWBYTES + nl * 4;
+                    const int J = (p / (4 / JPP)) * 4 + (p % (4 / JPP)) * JPP + jj;
+#pragma unroll
+                    for (int f = 0; f < C::TI; ++f) *(f32x4*)(lrow + f * 16) = acc[f][J] + bias4[f];
+                }
+                __syncthreads();
+#pragma unroll
+                for (int q = 0; q < NCH; ++q) {
+                    const int c = tid + q * C::NT;
+                    const int lr = c / CPR, ch = c - lr * CPR;
+                    float v[8];
+                    const f32x4 s0 = *(const f32x4*)(smem + lr * ROWBYTES + ch * 32);
+                    const f32x4 s1 = *(const f32x4*)(smem + lr * ROWBYTES + ch * 32 + 16);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float st = e < 4 ? s0[e] : s1[e - 4];
+                        const int sh = (e & 1) * 16;
+                        const float r = from_bits<T>((uint16_t)(ra[q][e >> 1] >> sh)) + from_bits<T>((uint16_t)(rb[q][e >> 1] >> sh));
+                        v[e] = st + r;
+                    }
+                    u32x4 oh, ol;
+#pragma unroll
+                    for (int e = 0; e < 8; e += 2) {
+                        const uint16_t h0 = to_bits<T>(v[e]), h1 = to_bits<T>(v[e + 1]);
+                        oh[e >> 1] = (uint32_t)h0 | ((uint32_t)h1 << 16);
+                        ol[e >> 1] = pack2_nosat<T>(v[e] - from_bits<T>(h0), v[e + 1] - from_bits<T>(h1));
+                    }
+                    if (!(g.ablate & 8)) {
+                        *(u32x4*)(out_hi + orow_q[q] + n0 + ch * 8) = oh;
+                        *(u32x4*)(out_lo + orow_q[q] + n0 + ch * 8) = ol;
+                    }
+                    float s1s = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+                    s1s = row8_sum8(s1s);
+                    const float mg = s1s * (1.0f / 64.0f);
+                    float s2 = 0.f;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float d = v[e] - mg;
+                        s2 = fmaf(d, d, s2);
+                    }
+                    s2 = row8_sum8(s2);
+                    if ((ch & 7) == 0) *(float2*)(statbuf + (tile_row(p, lr) * GR + (ch >> 3)) * 2) = float2{s1s, s2};
+                }
+                __syncthreads();
+            }
+            for (int i = tid; i < C::BM * GR; i += C::NT) {
+                const int trow = i / GR, gi = i - trow * GR;
+                if (!(g.ablate & 8))
+                    *(float2*)(g.stats_out + ((size_t)(m0 + trow) * (g.N / 64) + ((n0 >> 6) + gi)) * 2) = *(const float2*)(statbuf + i * 2);
+            }
+            __syncthreads();
+            if (has_next) {   // restart the ring on the next tile (issue pointers already point at it)
+                issue(2, 0, 0, true); issue(0, 0, 0, true); issue(3, 0, 0, true); issue(1, 0, 0, true);
+                issue(2, 1, 1, true); issue(0, 1, 1, true); issue(3, 1, 1, true);
+                wait_vm<C::INFLIGHT>();
+                bar();
+                if (wr) bar();
+            }
+        }
+        if (!has_next) break;
+        t += tw.nloc;
+        m0 = nm0;
+        n0 = nn0;
+    }
+    wait_vm<0>();   // the ring's run-ahead DMAs must have landed before the LDS is released
+    if constexpr (!RESID) {
+        if (!wr) bar();   // pair the extra barrier of the staggered group
+    }
+}
+
+template <class T, int EPI, class C>
+static hipError_t launch8(const GemmArgs& a, hipStream_t s) {
+    auto kern = gemm8_kernel<T, EPI, C>;
+    constexpr int LDS = (EPI == EPI_BIAS_RESID_LN) ? ((128 * (C::BN * 4 + 16) + C::BM * (C::BN / 64) * 8) > C::RING ? (128 * (C::BN * 4 + 16) + C::BM * (C::BN / 64) * 8) : C::RING) : C::RING;
+    static bool attr_done[64] = {};   // per device: the LDS opt-in is a per-device function attribute
+    int dev = 0;
+    hipGetDevice(&dev);
+    if (dev < 0 || dev >= 64 || !attr_done[dev]) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if (e != hipSuccess) return e;
+        if (dev >= 0 && dev < 64) attr_done[dev] = true;
+    }
+    const int tiles = (a.M / C::BM) * (a.N / C::BN);
+    int grid = tiles < 256 ? tiles : 256;
+    grid &= ~7;
+    if (grid < 8) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(C::NT), LDS, s, a);
+    return hipGetLastError();
+}
+
+bool gemm8_supported(int epi, const GemmArgs& a, int bn) {
+    if (epi != EPI_BIAS && epi != EPI_BIAS_GELU && epi != EPI_BIAS_RESID_LN) return false;
+    if (bn != 256 && bn != 192) return false;
+    if (a.M % 256 || a.N % bn || a.K % 128 || a.K < 256) return false;
+    if ((size_t)a.M * a.K * 2 >= (1ull << 32) || (size_t)a.w_rows * a.K * 2 >= (1ull << 32)) return false;   // 32-bit per-lane offsets
+    if ((a.M / 256) * (a.N / bn) < 8) return false;
+    if (epi == EPI_BIAS_RESID_LN) return a.ldo == a.N && a.plane && a.stats_out && !a.out_blocked;
+    return a.ldo == a.N && (!a.out_blocked || (a.N % 64 == 0 && bn == 256));
+}
+
+hipError_t gemm8_launch(int dtype, int epi, const GemmArgs& a, int bn, hipStream_t s) {
+    if (!gemm8_supported(epi, a, bn)) return hipErrorInvalidValue;
+#define VP_G8(TY)                                                                                                       \
+    do {                                                                                                                \
+        if (bn == 256) {                                                                                                \
+            if (epi == EPI_BIAS) return launch8<TY, EPI_BIAS, G8<256>>(a, s);                                           \
+            if (epi == EPI_BIAS_GELU) return launch8<TY, EPI_BIAS_GELU, G8<256>>(a, s);                                 \
+            return launch8<TY, EPI_BIAS_RESID_LN, G8<256>>(a, s);                                                       \
+        }                                                                                                               \
+        if (epi == EPI_BIAS) return launch8<TY, EPI_BIAS, G8<192>>(a, s);                                               \
+        if (epi == EPI_BIAS_GELU) return launch8<TY, EPI_BIAS_GELU, G8<192>>(a, s);                                     \
+        return launch8<TY, EPI_BIAS_RESID_LN, G8<192>>(a, s);                                                           \
+    } while (0)
+    if (dtype == DT_F16) VP_G8(F16);
+    VP_G8(BF16);
+#undef VP_G8
+}
+
+}  // namespace vp

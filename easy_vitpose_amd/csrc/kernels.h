@@ -60,6 +60,10 @@ struct GemmArgs {
     int ablate;           // profiling only (tools/gemm_ablate.py): 1 = no operand loads after the prologue, 2 = every tile loads the A rows of m-tile 0 (A L2-resident), 8 = no epilogue stores
 };
 hipError_t gemm_launch(int dtype, int epi, const GemmArgs& a, hipStream_t s);
+// 8-phase persistent kernel (gemm8.hip): 256 x bn tiles (bn = 256 or 192), EPI_BIAS / EPI_BIAS_GELU / EPI_BIAS_RESID_LN.
+// Selected through GemmArgs::variant 16 (bn 256) / 17 (bn 192) in gemm_launch.
+bool gemm8_supported(int epi, const GemmArgs& a, int bn);
+hipError_t gemm8_launch(int dtype, int epi, const GemmArgs& a, int bn, hipStream_t s);
 int gemm_tile_bn(int variant);   // BN of a tile configuration (number of n-tiles = ceil(N / BN))
 // fill a 16-bit buffer with pseudo-random values in [-1, 1) (benchmark operands)
 hipError_t fill_random16(int dtype, uint16_t* p, size_t n, uint32_t seed, hipStream_t s);

@@ -81,6 +81,7 @@ struct vp_ctx {
     float *hm = nullptr, *kp = nullptr, *tok = nullptr;
     float* hm_keep = nullptr;         // flip-test: heatmaps of the un-flipped crops while the flipped pass runs
     int32_t* partner = nullptr;       // flip-test: mirror joint per joint
+    int gemm8_mask = 0x7;             // kernel families on the 8-phase kernel at large batch: bit VP_PROF_GEMM_PROJ / _FC1 / _QKV (VP_GEMM8)
     bool persist_gemm = true;         // qkv / fc1 as persistent workgroups at large batch (VP_PERSIST=0: one tile per workgroup)
     int order_mask = 8;               // tile walk last-to-first per GEMM: bit0 qkv, bit1 proj, bit2 fc1, bit3 fc2 (VP_ORDER)
     bool blocked_hid = true;          // mlp hidden activations in the 64x64-blocked layout (VP_BLOCKED_HID=0: row-major)
@@ -355,6 +356,20 @@ int gemm(vp_ctx* c, int fam, int epi, const uint16_t* A, const uint16_t* W, cons
         g.plane = ln->plane; g.stats_out = ln->stats_out; g.rowstat = ln->rowstat; g.ln_s = ln->ln_s;
         if (ln->tiles_out) *ln->tiles_out = N / 64;   // partial statistics are written per 64 columns, whatever the tile
     }
+    // large batches: the 8-phase persistent kernel (gemm8.hip), one 512-thread workgroup per CU on 256 x 256 (wide GEMMs) or
+    // 256 x 192 (N = D: 768 = 4 x 192, three full rounds of 256 workgroups at batch 256) tiles, when every CU gets >= 2 tiles
+    if (c->gemm_variant[fam] < 0 && (c->gemm8_mask >> fam) & 1 &&
+        (epi == vp::EPI_BIAS || epi == vp::EPI_BIAS_GELU || epi == vp::EPI_BIAS_RESID_LN) && M % 256 == 0) {
+        const bool wide = epi != vp::EPI_BIAS_RESID_LN;
+        int bn = 0;
+        if (wide) bn = (N % 256 == 0) ? 256 : (N % 192 == 0 ? 192 : 0);
+        else bn = (N % 192 == 0 && (long)(M / 256) * (N / 192) % 256 == 0) ? 192 : (N % 256 == 0 ? 256 : (N % 192 == 0 ? 192 : 0));
+        if (bn && (long)(M / 256) * (N / bn) >= 512 && vp::gemm8_supported(epi, g, bn)) {
+            g.variant = bn == 256 ? 16 : 17;
+            g.group_m = 8;
+            g.persist = 0;
+        }
+    }
     const double par = (epi == vp::EPI_DECONV) ? 4.0 : 1.0;
     const double Nalg = (epi == vp::EPI_HEATMAP) ? (double)c->Kp : (double)N;   // heatmap: N counts the hi + lo weight rows
     const double flops = 2.0 * M * Nalg * K * par;
@@ -494,6 +509,7 @@ int vp_create(vp_handle* out, const vp_config* cfg) {
     if (const char* f = getenv("VP_BLOCKED_HID")) c->blocked_hid = atoi(f) != 0;
     if (const char* f = getenv("VP_ORDER")) c->order_mask = atoi(f);
     if (const char* f = getenv("VP_PERSIST")) c->persist_gemm = atoi(f) != 0;
+    if (const char* f = getenv("VP_GEMM8")) c->gemm8_mask = atoi(f);
     if (c->fuse_ln) {
         if ((rc = dalloc(c, &c->ln_part, M * (size_t)(D / 64) * 2))) return bail(rc);
         if ((rc = dalloc(c, &c->rowstat, M * 2))) return bail(rc);
@@ -986,6 +1002,157 @@ VP_API int vp_dbg_gemm_bench(int32_t device, int32_t dtype, int32_t epi, int32_t
     return dbg_finish(c, rc);
 }
 
+
+// ---- production-configuration GEMM taps (tests/test_gpu_gemm_cfgs.py, tools/gemm8_check.py) ----
+}  // extern "C"
+namespace {
+// a GEMM launch on RANDOM device operands in any production configuration: epi = kernels.h GemmEpi 0, 1 (optionally with the
+// LayerNorm-consumer fold), 2, 3, 6; flags: 1 persist, 2 out_blocked, 4 a_blocked, 8 reverse, 16 LayerNorm-consumer fold
+struct RandCase {
+    vp::GemmArgs g{};
+    size_t out_bytes = 0, stats_floats = 0;
+    void* out[2] = {nullptr, nullptr};
+    float* stats[2] = {nullptr, nullptr};
+};
+int make_rand_case(vp_ctx* c, RandCase& rc, int epi, int flags, int M, int N, int K, int nout) {
+    uint16_t *dA, *dW, *dAux16 = nullptr;
+    float *dB, *dAux32 = nullptr, *dRow = nullptr, *dS = nullptr;
+    int r;
+    const size_t MN = (size_t)M * N, wrows = pad128(N);
+    if ((r = dalloc(c, &dA, (size_t)M * K)) || (r = dalloc(c, &dW, wrows * K)) || (r = dalloc(c, &c->zero, (size_t)256))) return r;
+    vp::fill_random16(c->dtype, dA, (size_t)M * K, 1u, nullptr);
+    vp::fill_random16(c->dtype, dW, wrows * K, 2u, nullptr);
+    std::vector<float> hb(wrows), hs(wrows), hr((size_t)M * 2);
+    uint32_t lcg = 12345u;
+    auto rnd = [&]() { lcg = lcg * 1664525u + 1013904223u; return (float)((lcg >> 8) & 0xffff) / 65536.f - 0.5f; };
+    for (auto& v : hb) v = rnd();
+    for (auto& v : hs) v = 4.f * rnd();
+    for (size_t i = 0; i < (size_t)M; ++i) { hr[2 * i] = 0.2f * rnd(); hr[2 * i + 1] = 1.f + 0.4f * rnd(); }
+    if ((r = upload_f32(c, &dB, hb.data(), wrows))) return r;
+    vp::GemmArgs& g = rc.g;
+    g.A = dA; g.W = dW; g.bias = dB; g.M = M; g.N = N; g.K = K; g.ldo = N; g.zero = c->zero; g.Kp = c->Kp;
+    g.w_rows = (int)wrows;
+    g.persist = (flags & 1) != 0; g.out_blocked = (flags & 2) != 0; g.a_blocked = (flags & 4) != 0; g.reverse = (flags & 8) != 0;
+    if (flags & 16) {
+        if ((r = upload_f32(c, &dRow, hr.data(), (size_t)M * 2)) || (r = upload_f32(c, &dS, hs.data(), wrows))) return r;
+        g.rowstat = dRow; g.ln_s = dS;
+    }
+    if (epi == vp::EPI_BIAS || epi == vp::EPI_BIAS_GELU) {
+        rc.out_bytes = MN * 2;
+    } else if (epi == vp::EPI_BIAS_RESID || epi == vp::EPI_POS) {
+        rc.out_bytes = MN * 4;
+        const size_t na = epi == vp::EPI_BIAS_RESID ? MN : (size_t)192 * N;
+        if ((r = dalloc(c, &dAux32, na))) return r;
+        std::vector<float> ha(na);
+        for (auto& v : ha) v = 2.f * rnd();
+        HIPCHK(c, hipMemcpy(dAux32, ha.data(), na * 4, hipMemcpyHostToDevice));
+        g.aux = dAux32;
+    } else if (epi == vp::EPI_BIAS_RESID_LN) {
+        rc.out_bytes = MN * 4;   // hi plane + lo plane
+        rc.stats_floats = (size_t)M * (N / 64) * 2;
+        if ((r = dalloc(c, &dAux16, 2 * MN))) return r;
+        vp::fill_random16(c->dtype, dAux16, MN, 3u, nullptr);
+        vp::fill_random16(c->dtype, dAux16 + MN, MN, 4u, nullptr);
+        g.aux = (const float*)dAux16;
+        g.plane = MN;
+    } else {
+        return fail(c, VP_ERR_INVALID, "unsupported epilogue for the random GEMM case");
+    }
+    for (int i = 0; i < nout; ++i) {
+        char* o;
+        if ((r = dalloc(c, &o, rc.out_bytes))) return r;
+        HIPCHK(c, hipMemset(o, 0xff, rc.out_bytes));
+        rc.out[i] = o;
+        if (rc.stats_floats) {
+            if ((r = dalloc(c, &rc.stats[i], rc.stats_floats))) return r;
+            HIPCHK(c, hipMemset(rc.stats[i], 0xff, rc.stats_floats * 4));
+        }
+    }
+    HIPCHK(c, hipDeviceSynchronize());
+    return VP_OK;
+}
+}  // namespace
+extern "C" {
+
+// average milliseconds per launch of one production GEMM configuration on random operands
+VP_API int vp_dbg_gemm_bench2(int32_t device, int32_t dtype, int32_t epi, int32_t variant, int32_t group_m, int32_t flags, int32_t M,
+                              int32_t N, int32_t K, int32_t iters, float* ms_out) {
+    if (M <= 0 || N <= 0 || K <= 0 || K % 64 || iters <= 0 || !ms_out) return fail(nullptr, VP_ERR_INVALID, "bad gemm bench shape");
+    vp_ctx* c = dbg_ctx(device, dtype);
+    if (!c) return VP_ERR_HIP;
+    RandCase rc;
+    int r = make_rand_case(c, rc, epi, flags, M, N, K, 1);
+    if (r) return dbg_finish(c, r);
+    vp::GemmArgs g = rc.g;
+    g.variant = variant & 0xff; g.group_m = group_m; g.ablate = variant >> 8;
+    g.out = rc.out[0]; g.stats_out = rc.stats[0];
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    hipError_t e = hipSuccess;
+    for (int i = 0; i < 2 && e == hipSuccess; ++i) e = vp::gemm_launch(c->dtype, epi, g, nullptr);
+    hipDeviceSynchronize();
+    hipEventRecord(e0, nullptr);
+    for (int i = 0; i < iters && e == hipSuccess; ++i) e = vp::gemm_launch(c->dtype, epi, g, nullptr);
+    hipEventRecord(e1, nullptr);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, e0, e1);
+    *ms_out = ms / iters;
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    if (e != hipSuccess) return dbg_finish(c, fail(c, VP_ERR_HIP, std::string("gemm bench2: ") + hipGetErrorString(e)));
+    return dbg_finish(c, VP_OK);
+}
+
+// run two configurations of the same GEMM on the same random operands `reps` times each and compare every output byte
+// (and the row statistics): the race / schedule screen for kernels whose arithmetic order is identical by construction
+VP_API int vp_dbg_gemm_compare(int32_t device, int32_t dtype, int32_t epi, int32_t variant_a, int32_t group_a, int32_t flags_a,
+                               int32_t variant_b, int32_t group_b, int32_t flags_b, int32_t M, int32_t N, int32_t K, int32_t reps,
+                               uint64_t* n_mismatch, double* max_abs_diff) {
+    if (M <= 0 || N <= 0 || K <= 0 || K % 64 || reps <= 0 || !n_mismatch || !max_abs_diff) return fail(nullptr, VP_ERR_INVALID, "bad gemm compare shape");
+    if ((flags_a & (2 | 4 | 16)) != (flags_b & (2 | 4 | 16))) return fail(nullptr, VP_ERR_INVALID, "layout / fold flags must agree");
+    vp_ctx* c = dbg_ctx(device, dtype);
+    if (!c) return VP_ERR_HIP;
+    RandCase rc;
+    int r = make_rand_case(c, rc, epi, flags_a, M, N, K, 2);
+    if (r) return dbg_finish(c, r);
+    *n_mismatch = 0; *max_abs_diff = 0.0;
+    std::vector<uint16_t> ha(rc.out_bytes / 2), hb2(rc.out_bytes / 2);
+    std::vector<float> sa(rc.stats_floats), sb(rc.stats_floats);
+    for (int rep = 0; rep < reps; ++rep) {
+        for (int w = 0; w < 2; ++w) {
+            vp::GemmArgs g = rc.g;
+            const int fl = w ? flags_b : flags_a;
+            g.variant = w ? variant_b : variant_a; g.group_m = w ? group_b : group_a;
+            g.persist = (fl & 1) != 0; g.reverse = (fl & 8) != 0;
+            g.out = rc.out[w]; g.stats_out = rc.stats[w];
+            hipMemsetAsync(rc.out[w], 0xff, rc.out_bytes, nullptr);
+            hipError_t e = vp::gemm_launch(c->dtype, epi, g, nullptr);
+            if (e != hipSuccess) return dbg_finish(c, fail(c, VP_ERR_HIP, std::string("gemm compare launch ") + (w ? "B: " : "A: ") + hipGetErrorString(e)));
+        }
+        hipError_t e = hipDeviceSynchronize();
+        if (e == hipSuccess) e = hipMemcpy(ha.data(), rc.out[0], rc.out_bytes, hipMemcpyDeviceToHost);
+        if (e == hipSuccess) e = hipMemcpy(hb2.data(), rc.out[1], rc.out_bytes, hipMemcpyDeviceToHost);
+        if (e == hipSuccess && rc.stats_floats) e = hipMemcpy(sa.data(), rc.stats[0], rc.stats_floats * 4, hipMemcpyDeviceToHost);
+        if (e == hipSuccess && rc.stats_floats) e = hipMemcpy(sb.data(), rc.stats[1], rc.stats_floats * 4, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) return dbg_finish(c, fail(c, VP_ERR_HIP, std::string("gemm compare: ") + hipGetErrorString(e)));
+        const bool f32out = (epi == vp::EPI_BIAS_RESID || epi == vp::EPI_POS);
+        if (f32out) {
+            const float* fa = (const float*)ha.data(); const float* fb = (const float*)hb2.data();
+            for (size_t i = 0; i < rc.out_bytes / 4; ++i)
+                if (std::memcmp(&fa[i], &fb[i], 4)) { ++*n_mismatch; const double d = std::fabs((double)fa[i] - (double)fb[i]); if (!(d <= *max_abs_diff)) *max_abs_diff = d; }
+        } else {
+            for (size_t i = 0; i < ha.size(); ++i)
+                if (ha[i] != hb2[i]) {
+                    ++*n_mismatch;
+                    const double d = std::fabs((double)host_from_bits(ha[i], c->dtype) - (double)host_from_bits(hb2[i], c->dtype));
+                    if (!(d <= *max_abs_diff)) *max_abs_diff = d;
+                }
+        }
+        for (size_t i = 0; i < sa.size(); ++i)
+            if (std::memcmp(&sa[i], &sb[i], 4)) { ++*n_mismatch; const double d = std::fabs((double)sa[i] - (double)sb[i]); if (!(d <= *max_abs_diff)) *max_abs_diff = d; }
+    }
+    return dbg_finish(c, VP_OK);
+}
 
 // frame + crop geometry -> the uint8 [n,256,192,3] crops the model is fed (device crop/pad/resize kernel alone)
 VP_API int vp_dbg_crop_prep(int32_t device, const uint8_t* frame, int32_t fh, int32_t fw, const int32_t* crop_params, int32_t n, uint8_t* out) {
