@@ -24,7 +24,7 @@ DTYPES = {'fp16': VP_DTYPE_F16, 'f16': VP_DTYPE_F16, 'bf16': VP_DTYPE_BF16}
 SYMBOLS = ['vp_abi_version', 'vp_create', 'vp_load_weights', 'vp_infer', 'vp_infer_device', 'vp_infer_frame', 'vp_infer_flip', 'vp_infer_heatmaps',
            'vp_infer_tokens', 'vp_decode_only', 'vp_stream', 'vp_synchronize', 'vp_set_profiling',
            'vp_reset_profile', 'vp_get_profile', 'vp_destroy', 'vp_last_error',
-           'vp_dbg_gemm', 'vp_dbg_attention', 'vp_dbg_layernorm', 'vp_dbg_deconv', 'vp_dbg_gemm_bench', 'vp_dbg_gemm_bench2', 'vp_dbg_gemm_compare', 'vp_dbg_gemm_timeline', 'vp_dbg_peak', 'vp_dbg_crop_prep']
+           'vp_dbg_gemm', 'vp_dbg_attention', 'vp_dbg_layernorm', 'vp_dbg_deconv', 'vp_dbg_gemm_bench', 'vp_dbg_gemm_bench2', 'vp_dbg_gemm_compare', 'vp_dbg_gemm8_timeline', 'vp_dbg_gemm_timeline', 'vp_dbg_peak', 'vp_dbg_crop_prep']
 
 
 class HipExtensionMissing(RuntimeError):
@@ -99,6 +99,7 @@ def load_library():
     lib.vp_dbg_gemm_bench.argtypes = [C.c_int32] * 9 + [C.POINTER(C.c_float)]
     lib.vp_dbg_gemm_bench2.argtypes = [C.c_int32] * 10 + [C.POINTER(C.c_float)]
     lib.vp_dbg_gemm_compare.argtypes = [C.c_int32] * 13 + [C.POINTER(C.c_uint64), C.POINTER(C.c_double)]
+    lib.vp_dbg_gemm8_timeline.argtypes = [C.c_int32] * 9 + [C.POINTER(C.c_uint64), C.c_int32]
     lib.vp_dbg_gemm_timeline.argtypes = [C.c_int32] * 6 + [C.POINTER(C.c_uint64), C.c_int32]
     lib.vp_dbg_peak.argtypes = [C.c_int32, C.c_int32, C.POINTER(C.c_double)]
     for name in SYMBOLS:

@@ -69,6 +69,12 @@ template <> __device__ __forceinline__ f32x4 mfma16<BF16>(u32x4 a, u32x4 b, f32x
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
+// LayerNorm folded into a GEMM epilogue: rstd * (acc - mean * s) + b as two explicit fused multiply-adds,
+// so that every kernel that applies it rounds identically (bit-identity between tile configurations is the race screen)
+__device__ __forceinline__ float ln_fold(float acc, float mean, float s, float rstd, float b) {
+    return __builtin_fmaf(__builtin_fmaf(-mean, s, acc), rstd, b);
+}
+
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef __attribute__((address_space(1))) const void* gbl_ptr_t;
 

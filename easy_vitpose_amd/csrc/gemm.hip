@@ -24,6 +24,7 @@
 //    output-parity classes, each a GEMM with K = 4*Cin whose A rows are gathered
 //    (one row chunk per k-step, zero row at the border) straight by the
 //    global_load_lds source addresses -- no im2col buffer in HBM.
+#include <cstdlib>
 #include <type_traits>
 #include <utility>
 
@@ -635,9 +636,10 @@ __global__ __launch_bounds__(C::NT, 2) void gemm_kernel(GemmArgs g) {
                     if (LN_CONSUMER && ln_in) {   // LayerNorm folded into this GEMM: rstd * (x.W' - mean * sum_k W') + c
                         const float mu = ln_mean[p * JP + jj], rs = ln_rstd[p * JP + jj];
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] = (v[r] - mu * ln_s4[i][r]) * rs;
+                        for (int r = 0; r < 4; ++r) v[r] = ln_fold(v[r], mu, ln_s4[i][r], rs, bias4[i][r]);
+                    } else {
+                        v += bias4[i];
                     }
-                    v += bias4[i];
                     if (EPI == EPI_BIAS_GELU) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
@@ -932,9 +934,10 @@ __global__ __launch_bounds__(C::NT, 2) void gemm_persist_kernel(GemmArgs g) {
                     if (ln_in) {
                         const float mu = ln_mean[p * JP + jj], rs = ln_rstd[p * JP + jj];
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] = (v[r] - mu * ln_s4[i][r]) * rs;
+                        for (int r = 0; r < 4; ++r) v[r] = ln_fold(v[r], mu, ln_s4[i][r], rs, bias4[i][r]);
+                    } else {
+                        v += bias4[i];
                     }
-                    v += bias4[i];
                     if (EPI == EPI_BIAS_GELU) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
@@ -1084,7 +1087,13 @@ int gemm_tile_bn(int variant) {
 
 hipError_t gemm_launch(int dtype, int epi, const GemmArgs& a, hipStream_t s) {
     if (a.K % 64 != 0 || a.M <= 0 || a.N <= 0) return hipErrorInvalidValue;
-    if (a.variant == 16 || a.variant == 17) return gemm8_launch(dtype, epi, a, a.variant == 16 ? 256 : 192, s);
+    if (a.variant == 16 || a.variant == 17) {
+        static const int stagger_env = [] { const char* e = getenv("VP_G8_STAGGER"); return e ? atoi(e) : -1; }();
+        if (stagger_env < 0) return gemm8_launch(dtype, epi, a, a.variant == 16 ? 256 : 192, s);
+        GemmArgs b = a;   // experiments: override the start stagger
+        b.stagger = stagger_env;
+        return gemm8_launch(dtype, epi, b, a.variant == 16 ? 256 : 192, s);
+    }
     if (a.persist) {   // persistent variant: wide 16-bit-output GEMMs on the default tile (a 256x256 instantiation spilled and was slower)
         if ((epi != EPI_BIAS && epi != EPI_BIAS_GELU) || a.variant != 8 || a.K % 128 || a.N % 8 || a.ldo != a.N || a.reverse ||
             a.M % Cfg8::BM || (size_t)a.M * a.K * 2 >= (1ull << 32) ||

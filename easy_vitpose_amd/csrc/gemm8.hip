@@ -194,7 +194,8 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs g) {
     // one K-tile: ring buffer B holds it; kn1 / kn2 = K-tile indices (relative to the ISSUE tile pointers) of the
     // K-tiles one and two ahead; sw = switch the issue pointers to the next tile after P1 (the K-tile two ahead, and
     // from then on everything issued, belongs to the next tile)
-    auto ktile = [&](auto Bc, int kn1, int kn2, bool sw, int nm0, int nn0) {
+    unsigned long long ks[4] = {0, 0, 0, 0};   // tools/gemm8_timeline.py (ablate 32): P4 wait of K-tiles 0 and 1 of a tile, begin / end
+    auto ktile = [&](auto Bc, int kn1, int kn2, bool sw, int nm0, int nn0, int stamp = -1) {
         constexpr int B = decltype(Bc)::value;
         const char* sb = smem + B * C::BUF;
         // ---------------- P1
@@ -257,7 +258,9 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs g) {
         bar();
         // ---------------- P4
         issue(3, B, kn2);
+        if (stamp >= 0) ks[2 * stamp] = __builtin_readcyclecounter();
         wait_vm<C::INFLIGHT>();   // everything up to P1's DMA has landed (own share): K-tile t+1 is complete
+        if (stamp >= 0) ks[2 * stamp + 1] = __builtin_readcyclecounter();
         bar();
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -270,6 +273,10 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs g) {
         bar();
     };
 
+    if (g.stagger > 0) {   // XCD x starts x * stagger sleep quanta late: the XCDs' store bursts no longer coincide
+        const int n = (blockIdx.x & 7) * g.stagger;
+        for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(127);
+    }
     // ---- prologue of the first tile: K-tile 0 complete, W0 / X0 / W1 of K-tile 1 in flight ----
     int t = tw.j0, m0, n0;
     tw.origin(t, g.reverse, C::BM, C::BN, m0, n0);
@@ -285,13 +292,17 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs g) {
         const bool has_next = t + tw.nloc < tw.cnt;
         int nm0 = m0, nn0 = n0;   // no next tile: the ring keeps fetching (valid, unused) K-tiles 0 / 1 of this tile
         if (has_next) tw.origin(t + tw.nloc, g.reverse, C::BM, C::BN, nm0, nn0);
+        const bool tl = (g.ablate & 32) != 0;
+        unsigned long long ts0 = 0, ts1 = 0;
+        if (tl) ts0 = __builtin_readcyclecounter();
         for (int kt = 0; kt < nk - 2; kt += 2) {
-            ktile(std::integral_constant<int, 0>{}, kt + 1, kt + 2, false, 0, 0);
-            ktile(std::integral_constant<int, 1>{}, kt + 2, kt + 3, false, 0, 0);
+            ktile(std::integral_constant<int, 0>{}, kt + 1, kt + 2, false, 0, 0, (tl && kt == 0) ? 0 : -1);
+            ktile(std::integral_constant<int, 1>{}, kt + 2, kt + 3, false, 0, 0, (tl && kt == 0) ? 1 : -1);
         }
         // last two K-tiles: K-tile nk-2 still issues X1 of K-tile nk-1 from this tile, everything after it is the next tile's
         ktile(std::integral_constant<int, 0>{}, nk - 1, 0, true, nm0, nn0);
         ktile(std::integral_constant<int, 1>{}, 0, 1, false, 0, 0);
+        if (tl) ts1 = __builtin_readcyclecounter();
 
         // ---------------- epilogue of tile (m0, n0) ----------------
         if constexpr (!RESID) {
@@ -328,9 +339,10 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs g) {
                         f32x4 v = acc[f][J];
                         if constexpr (LN) {
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) v[r] = (v[r] - st[J].x * s4[f][r]) * st[J].y;
+                            for (int r = 0; r < 4; ++r) v[r] = ln_fold(v[r], st[J].x, s4[f][r], st[J].y, bias4[f][r]);
+                        } else {
+                            v += bias4[f];
                         }
-                        v += bias4[f];
                         if (EPI == EPI_BIAS_GELU) {
 #pragma unroll
                             for (int r = 0; r < 4; ++r) v[r] = gelu8(v[r]);
@@ -341,8 +353,13 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs g) {
                     uint16_t* dst = obase + (size_t)(J >> 2) * step128 + (size_t)(J & 3) * step16;
                     if (store) {
                         if constexpr (C::TI == 4) {
-                            *(u32x4*)dst = u32x4{o[0], o[1], o[2], o[3]};
-                            *(u32x4*)(dst + 8) = u32x4{o[4], o[5], o[6], o[7]};
+                            if (g.ablate & 64) {   // experiment: streaming (non-temporal) stores
+                                __builtin_nontemporal_store(u32x4{o[0], o[1], o[2], o[3]}, (u32x4*)dst);
+                                __builtin_nontemporal_store(u32x4{o[4], o[5], o[6], o[7]}, (u32x4*)(dst + 8));
+                            } else {
+                                *(u32x4*)dst = u32x4{o[0], o[1], o[2], o[3]};
+                                *(u32x4*)(dst + 8) = u32x4{o[4], o[5], o[6], o[7]};
+                            }
                         } else {   // 12 columns = 24 bytes, 8-byte aligned
                             *(u32x2*)dst = u32x2{o[0], o[1]};
                             *(u32x2*)(dst + 4) = u32x2{o[2], o[3]};
@@ -353,6 +370,14 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs g) {
             };
             if (g.rowstat != nullptr) epilogue(std::true_type{});
             else epilogue(std::false_type{});
+            if (tl && lane == 0 && (wave & 3) == 0) {   // stamps of waves 0 and 4 (one per stagger group): [wg][group][tile < 16][8]
+                const int ti = (t - tw.j0) / tw.nloc;
+                if (ti < 16) {
+                    unsigned long long* sp = (unsigned long long*)g.stats_out + (((size_t)blockIdx.x * 2 + wr) * 16 + ti) * 8;
+                    sp[0] = ts0; sp[1] = ts1; sp[2] = __builtin_readcyclecounter();
+                    sp[3] = ks[0]; sp[4] = ks[1]; sp[5] = ks[2]; sp[6] = ks[3];
+                }
+            }
         } else {
             // Residual epilogue through LDS (the ring is drained first and restarted afterwards: fc2's 48 K-tiles make
             // the tile boundary cheap).  Arithmetic and statistics order = gemm.hip's fused-LayerNorm producer.

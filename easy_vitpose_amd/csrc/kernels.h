@@ -57,6 +57,9 @@ struct GemmArgs {
     // persistent workgroups whose operand ring runs on across tile boundaries (gemm.hip gemm_persist_kernel):
     // EPI_BIAS / EPI_BIAS_GELU on the default tile, K % 128 == 0
     int persist;
+    // gemm8.hip: start of XCD x (= blockIdx & 7) delayed by x * stagger * 64 * 127 shader cycles, so that the eight XCDs reach
+    // their tile boundaries -- the store bursts of the epilogue -- at different times instead of saturating HBM together
+    int stagger;
     int ablate;           // profiling only (tools/gemm_ablate.py): 1 = no operand loads after the prologue, 2 = every tile loads the A rows of m-tile 0 (A L2-resident), 8 = no epilogue stores
 };
 hipError_t gemm_launch(int dtype, int epi, const GemmArgs& a, hipStream_t s);

@@ -81,6 +81,7 @@ struct vp_ctx {
     float *hm = nullptr, *kp = nullptr, *tok = nullptr;
     float* hm_keep = nullptr;         // flip-test: heatmaps of the un-flipped crops while the flipped pass runs
     int32_t* partner = nullptr;       // flip-test: mirror joint per joint
+    int g8_stagger = 0;               // gemm8: start delay per XCD in sleep quanta (VP_G8_STAGGER)
     int gemm8_mask = 0x7;             // kernel families on the 8-phase kernel at large batch: bit VP_PROF_GEMM_PROJ / _FC1 / _QKV (VP_GEMM8)
     bool persist_gemm = true;         // qkv / fc1 as persistent workgroups at large batch (VP_PERSIST=0: one tile per workgroup)
     int order_mask = 8;               // tile walk last-to-first per GEMM: bit0 qkv, bit1 proj, bit2 fc1, bit3 fc2 (VP_ORDER)
@@ -358,7 +359,10 @@ int gemm(vp_ctx* c, int fam, int epi, const uint16_t* A, const uint16_t* W, cons
     }
     // large batches: the 8-phase persistent kernel (gemm8.hip), one 512-thread workgroup per CU on 256 x 256 (wide GEMMs) or
     // 256 x 192 (N = D: 768 = 4 x 192, three full rounds of 256 workgroups at batch 256) tiles, when every CU gets >= 2 tiles
-    if (c->gemm_variant[fam] < 0 && (c->gemm8_mask >> fam) & 1 &&
+    // (attn.proj, K = N = D, is HBM-bound and stays on the 192 x 128 tile with two workgroups per CU: measured 105 vs 112 us;
+    // bit 3 of VP_GEMM8 moves it too)
+    const bool is_proj = epi == vp::EPI_BIAS_RESID_LN && K <= N;
+    if (c->gemm_variant[fam] < 0 && (c->gemm8_mask >> fam) & 1 && (!is_proj || (c->gemm8_mask & 8)) &&
         (epi == vp::EPI_BIAS || epi == vp::EPI_BIAS_GELU || epi == vp::EPI_BIAS_RESID_LN) && M % 256 == 0) {
         const bool wide = epi != vp::EPI_BIAS_RESID_LN;
         int bn = 0;
@@ -368,6 +372,7 @@ int gemm(vp_ctx* c, int fam, int epi, const uint16_t* A, const uint16_t* W, cons
             g.variant = bn == 256 ? 16 : 17;
             g.group_m = 8;
             g.persist = 0;
+            g.stagger = c->g8_stagger;
         }
     }
     const double par = (epi == vp::EPI_DECONV) ? 4.0 : 1.0;
@@ -510,6 +515,7 @@ int vp_create(vp_handle* out, const vp_config* cfg) {
     if (const char* f = getenv("VP_ORDER")) c->order_mask = atoi(f);
     if (const char* f = getenv("VP_PERSIST")) c->persist_gemm = atoi(f) != 0;
     if (const char* f = getenv("VP_GEMM8")) c->gemm8_mask = atoi(f);
+    if (const char* f = getenv("VP_G8_STAGGER")) c->g8_stagger = atoi(f);
     if (c->fuse_ln) {
         if ((rc = dalloc(c, &c->ln_part, M * (size_t)(D / 64) * 2))) return bail(rc);
         if ((rc = dalloc(c, &c->rowstat, M * 2))) return bail(rc);
@@ -1100,6 +1106,31 @@ VP_API int vp_dbg_gemm_bench2(int32_t device, int32_t dtype, int32_t epi, int32_
     *ms_out = ms / iters;
     hipEventDestroy(e0); hipEventDestroy(e1);
     if (e != hipSuccess) return dbg_finish(c, fail(c, VP_ERR_HIP, std::string("gemm bench2: ") + hipGetErrorString(e)));
+    return dbg_finish(c, VP_OK);
+}
+
+// tools/gemm8_timeline.py: one gemm8 launch (variant 16 / 17, epi 0 / 1) with cycle stamps of waves 0 and 4 of every workgroup:
+// stamps[wg][group][tile < 16][8] = (main loop begin, main loop end, epilogue end, P4 wait of K-tile 0 begin / end, of K-tile 1 begin / end, 0)
+VP_API int vp_dbg_gemm8_timeline(int32_t device, int32_t dtype, int32_t epi, int32_t variant, int32_t flags, int32_t ablate, int32_t M,
+                                 int32_t N, int32_t K, uint64_t* stamps, int32_t max_wg) {
+    if ((epi != 0 && epi != 1) || !stamps || max_wg < 256) return fail(nullptr, VP_ERR_INVALID, "bad timeline request");
+    vp_ctx* c = dbg_ctx(device, dtype);
+    if (!c) return VP_ERR_HIP;
+    RandCase rc;
+    int r = make_rand_case(c, rc, epi, flags, M, N, K, 1);
+    if (r) return dbg_finish(c, r);
+    unsigned long long* dS;
+    const size_t nst = (size_t)max_wg * 2 * 16 * 8;
+    if ((r = dalloc(c, &dS, nst))) return dbg_finish(c, r);
+    hipMemset(dS, 0, nst * 8);
+    vp::GemmArgs g = rc.g;
+    g.variant = variant; g.group_m = 8; g.out = rc.out[0];
+    hipError_t e = vp::gemm_launch(c->dtype, epi, g, nullptr);   // warm
+    g.ablate = 32 | ablate; g.stats_out = (float*)dS;
+    if (e == hipSuccess) e = vp::gemm_launch(c->dtype, epi, g, nullptr);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipMemcpy(stamps, dS, nst * 8, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return dbg_finish(c, fail(c, VP_ERR_HIP, std::string("gemm8 timeline: ") + hipGetErrorString(e)));
     return dbg_finish(c, VP_OK);
 }
 

@@ -205,6 +205,9 @@ VP_API int vp_dbg_gemm_bench2(int32_t device_id, int32_t dtype, int32_t epi, int
 VP_API int vp_dbg_gemm_compare(int32_t device_id, int32_t dtype, int32_t epi, int32_t variant_a, int32_t group_a, int32_t flags_a,
                                int32_t variant_b, int32_t group_b, int32_t flags_b, int32_t M, int32_t N, int32_t K, int32_t reps,
                                uint64_t* n_mismatch, double* max_abs_diff);
+/* tools/gemm8_timeline.py: cycle stamps of one gemm8 launch, stamps[max_wg >= 256][2 wave groups][16 tiles][8] */
+VP_API int vp_dbg_gemm8_timeline(int32_t device_id, int32_t dtype, int32_t epi, int32_t variant, int32_t flags, int32_t ablate,
+                                 int32_t M, int32_t N, int32_t K, uint64_t* stamps, int32_t max_wg);
 /* calibration of the box: kind 0/1 = MFMA-only loop 16x16x32 / 32x32x16 f16 (TFLOP/s), 2 = float4 copy (TB/s) */
 VP_API int vp_dbg_peak(int32_t device_id, int32_t kind, double* result);
 
