@@ -586,8 +586,18 @@ __global__ __launch_bounds__(C::NT, 2) void gemm_kernel(GemmArgs g) {
         // fused LayerNorm, consumer side: per-row (mean, rstd) of this lane's TJ fragment rows
         constexpr bool LN_CONSUMER = (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU);
         const bool ln_in = LN_CONSUMER && g.rowstat != nullptr;
+        // neutral defaults (mean 0, rstd 1: ln_fold(acc, 0, s, 1, b) == acc + b exactly), so that the arithmetic below is
+        // unconditional straight-line code; only the LOADS sit behind the wave-uniform `ln_in` branch.  (A per-element
+        // `if (ln_in)` around the fold compiled to a chain of scalar branches between the LDS staging writes, and that build
+        // was not run-to-run deterministic once several workgroups shared a CU: tools/gemm_selfcheck.py.)
         float ln_mean[LN_CONSUMER ? C::TJ : 1], ln_rstd[LN_CONSUMER ? C::TJ : 1];
         f32x4 ln_s4[LN_CONSUMER ? C::TI : 1];
+        if (LN_CONSUMER) {
+#pragma unroll
+            for (int i = 0; i < C::TI; ++i) ln_s4[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < C::TJ; ++j) { ln_mean[j] = 0.f; ln_rstd[j] = 1.f; }
+        }
         if (LN_CONSUMER && ln_in) {
 #pragma unroll
             for (int i = 0; i < C::TI; ++i) ln_s4[i] = *(const f32x4*)(g.ln_s + n0 + wn * C::WN + i * 16 + fg * 4);
@@ -633,7 +643,7 @@ __global__ __launch_bounds__(C::NT, 2) void gemm_kernel(GemmArgs g) {
 #pragma unroll
                 for (int i = 0; i < C::TI; ++i) {
                     f32x4 v = acc[i][p * JP + jj];
-                    if (LN_CONSUMER && ln_in) {   // LayerNorm folded into this GEMM: rstd * (x.W' - mean * sum_k W') + c
+                    if (LN_CONSUMER) {   // LayerNorm folded into this GEMM: rstd * (x.W' - mean * sum_k W') + c
                         const float mu = ln_mean[p * JP + jj], rs = ln_rstd[p * JP + jj];
 #pragma unroll
                         for (int r = 0; r < 4; ++r) v[r] = ln_fold(v[r], mu, ln_s4[i][r], rs, bias4[i][r]);
@@ -911,6 +921,10 @@ __global__ __launch_bounds__(C::NT, 2) void gemm_persist_kernel(GemmArgs g) {
         float ln_mean[C::TJ], ln_rstd[C::TJ];
 #pragma unroll
         for (int i = 0; i < C::TI; ++i) bias4[i] = (g.ablate & 64) ? f32x4{0.f, 0.f, 0.f, 0.f} : *(const f32x4*)(g.bias + n0 + wn * C::WN + i * 16 + fg * 4);
+#pragma unroll
+        for (int i = 0; i < C::TI; ++i) ln_s4[i] = f32x4{0.f, 0.f, 0.f, 0.f};   // neutral fold, see gemm_kernel
+#pragma unroll
+        for (int j = 0; j < C::TJ; ++j) { ln_mean[j] = 0.f; ln_rstd[j] = 1.f; }
         if (ln_in) {
 #pragma unroll
             for (int i = 0; i < C::TI; ++i) ln_s4[i] = *(const f32x4*)(g.ln_s + n0 + wn * C::WN + i * 16 + fg * 4);
@@ -931,12 +945,10 @@ __global__ __launch_bounds__(C::NT, 2) void gemm_persist_kernel(GemmArgs g) {
 #pragma unroll
                 for (int i = 0; i < C::TI; ++i) {
                     f32x4 v = acc[i][p * JP + jj];
-                    if (ln_in) {
+                    {
                         const float mu = ln_mean[p * JP + jj], rs = ln_rstd[p * JP + jj];
 #pragma unroll
                         for (int r = 0; r < 4; ++r) v[r] = ln_fold(v[r], mu, ln_s4[i][r], rs, bias4[i][r]);
-                    } else {
-                        v += bias4[i];
                     }
                     if (EPI == EPI_BIAS_GELU) {
 #pragma unroll
