@@ -83,3 +83,14 @@ def frame_case():
 def coco_flip_pairs():
     """Mirror joint pairs of the COCO-17 layout (left/right eye, ear, shoulder, elbow, wrist, hip, knee, ankle)."""
     return [[1, 2], [3, 4], [5, 6], [7, 8], [9, 10], [11, 12], [13, 14], [15, 16]]
+
+
+def peaked_plan():
+    """(variant, dataset, crops) of the peaked-checkpoint goldens: 136 / 136 / 100 / 1064 joints."""
+    return [('s', 'coco', 8), ('b', 'coco', 8), ('l', 'coco_25', 4), ('h', 'wholebody', 8)]
+
+
+def peaked_crops(n: int):
+    """Half blob crops, half uniform-noise crops (seeds 21 / 22)."""
+    from easy_vitpose_amd.synth import synthetic_crops
+    return np.concatenate([synthetic_crops(n // 2, 21, 'blobs'), synthetic_crops(n - n // 2, 22, 'noise')])

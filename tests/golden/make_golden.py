@@ -107,6 +107,9 @@ def import_reference():
 
 def build_ref(VitInference, ViTPose, dyn_model_import, dataset, variant, sd_np):
     cfg = dyn_model_import(dataset, variant)
+    # the reference's config modules share ONE dict per variant and set out_channels at import time only: a second dataset's
+    # model built later would keep the first one's K.  Set what ViTPose_<dataset>.py sets.
+    cfg['keypoint_head']['out_channels'] = int(sd_np['keypoint_head.final_layer.bias'].shape[0])
     model = ViTPose(cfg)
     model.eval()
     missing = model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd_np.items()})
@@ -218,6 +221,29 @@ def main():
         np.savez_compressed(os.path.join(HERE, f'model_{variant}_{dataset}.npz'), variant=variant, dataset=dataset,
                             n=n, kind=kind, crop_seed=7, weight_seed=0, heatmaps=hm_store.astype(np.float32),
                             keypoints=kps, stats=stats)
+
+    # ------------------------------------------------------- peaked-checkpoint goldens
+    # synthetic_state_dict(peaked=True): one Gaussian-like blob per joint, so the reference's own keypoints are
+    # well-conditioned on EVERY joint and can be asserted end to end (+-0.5 px, 1e-3) on the device.
+    from cases import peaked_plan, peaked_crops
+    for variant, dataset, n in peaked_plan():
+        shp = model_shape(variant, dataset)
+        sd = synthetic_state_dict(shp, seed=0, peaked=True)
+        V = build_ref(VitInference, ViTPose, dyn_model_import, dataset, variant, sd)
+        crops = peaked_crops(n)
+        kps, hm0 = [], None
+        with torch.no_grad():
+            for i in range(n):
+                kps.append(V._inference_torch(crops[i]))
+                if i == 0:
+                    hm0 = V._vit_pose(torch.from_numpy(V.pre_img(crops[0])[0])).numpy()
+        kps = np.concatenate(kps, 0).astype(np.float32)
+        sdt = O.to_torch_state_dict(sd)
+        mine = np.concatenate([O.inference_torch(sdt, shp.depth, shp.num_heads, crops[i]) for i in range(n)], 0)
+        print(f'peaked {variant}/{dataset}: {n} crops x {shp.num_keypoints} joints, confidences {kps[..., 2].min():.3f} .. {kps[..., 2].max():.3f}, '
+              f'oracle-vs-reference keypoints max|d| = {np.abs(mine - kps).max():.3e}')
+        np.savez_compressed(os.path.join(HERE, f'peaked_{variant}_{dataset}.npz'), variant=variant, dataset=dataset, n=n,
+                            keypoints=kps, heatmaps0=hm0[:, :16].astype(np.float32))
 
 
 if __name__ == '__main__':
