@@ -1,6 +1,2 @@
 cd $GRAFT_REPO_ROOT
-python tools/gemm_selfcheck.py 384 16 2>&1 | grep -v "noln"
-python tools/gemm_selfcheck.py 768 8 2>&1 | grep "cfg9 vs cfg9\|cfg1 vs cfg1"
-python tools/determinism_check.py s 16 3
-python tools/determinism_check.py b 8 2
-python tools/gemm8_check.py --reps 1 --no-bench
+timeout 900 python -m pytest tests/test_gpu_parity.py -q -s -k "peaked" 2>&1 | grep "peaked\]\|passed\|failed\|Error" | tail -40
