@@ -18,8 +18,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIBDIR = os.path.join(HERE, '_lib')
 LIB = os.path.join(LIBDIR, 'libvitpose_hip.so')
-SOURCES = ['gemm.hip', 'gemm8.hip', 'attention.hip', 'elementwise.hip', 'decode.hip', 'vitpose_api.hip']
-HEADERS = ['common.h', 'kernels.h', os.path.join('..', '..', 'include', 'vitpose_hip.h')]
+SOURCES = ['gemm.hip', 'gemm8.hip', 'gemm8d.hip', 'attention.hip', 'elementwise.hip', 'decode.hip', 'vitpose_api.hip']
+HEADERS = ['common.h', 'kernels.h', 'gemm8_common.h', os.path.join('..', '..', 'include', 'vitpose_hip.h')]
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-fvisibility=hidden',
          '-ffp-contract=fast', '-Wno-unused-result']
 

@@ -67,6 +67,7 @@ hipError_t gemm_launch(int dtype, int epi, const GemmArgs& a, hipStream_t s);
 // Selected through GemmArgs::variant 16 (bn 256) / 17 (bn 192) in gemm_launch.
 bool gemm8_supported(int epi, const GemmArgs& a, int bn);
 hipError_t gemm8_launch(int dtype, int epi, const GemmArgs& a, int bn, hipStream_t s);
+hipError_t gemm8_deferred_launch(int dtype, int epi, const GemmArgs& a, hipStream_t s);   // gemm8d.hip, variant 19
 int gemm_tile_bn(int variant);   // BN of a tile configuration (number of n-tiles = ceil(N / BN))
 // fill a 16-bit buffer with pseudo-random values in [-1, 1) (benchmark operands)
 hipError_t fill_random16(int dtype, uint16_t* p, size_t n, uint32_t seed, hipStream_t s);

@@ -81,6 +81,7 @@ struct vp_ctx {
     float *hm = nullptr, *kp = nullptr, *tok = nullptr;
     float* hm_keep = nullptr;         // flip-test: heatmaps of the un-flipped crops while the flipped pass runs
     int32_t* partner = nullptr;       // flip-test: mirror joint per joint
+    bool g8_deferred = false;         // wide GEMMs on the deferred-quadrant-epilogue variant of gemm8 (VP_G8_DEFERRED=1; measured slower)
     int g8_stagger = 0;               // gemm8: start delay per XCD in sleep quanta (VP_G8_STAGGER)
     int gemm8_mask = 0x7;             // kernel families on the 8-phase kernel at large batch: bit VP_PROF_GEMM_PROJ / _FC1 / _QKV (VP_GEMM8)
     bool persist_gemm = true;         // qkv / fc1 as persistent workgroups at large batch (VP_PERSIST=0: one tile per workgroup)
@@ -369,7 +370,7 @@ int gemm(vp_ctx* c, int fam, int epi, const uint16_t* A, const uint16_t* W, cons
         if (wide) bn = (N % 256 == 0) ? 256 : (N % 192 == 0 ? 192 : 0);
         else bn = (N % 192 == 0 && (long)(M / 256) * (N / 192) % 256 == 0) ? 192 : (N % 256 == 0 ? 256 : (N % 192 == 0 ? 192 : 0));
         if (bn && (long)(M / 256) * (N / bn) >= 512 && vp::gemm8_supported(epi, g, bn)) {
-            g.variant = bn == 256 ? 16 : 17;
+            g.variant = bn == 256 ? (wide && c->g8_deferred ? 19 : 16) : 17;
             g.group_m = 8;
             g.persist = 0;
             g.stagger = c->g8_stagger;
@@ -516,6 +517,7 @@ int vp_create(vp_handle* out, const vp_config* cfg) {
     if (const char* f = getenv("VP_PERSIST")) c->persist_gemm = atoi(f) != 0;
     if (const char* f = getenv("VP_GEMM8")) c->gemm8_mask = atoi(f);
     if (const char* f = getenv("VP_G8_STAGGER")) c->g8_stagger = atoi(f);
+    if (const char* f = getenv("VP_G8_DEFERRED")) c->g8_deferred = atoi(f) != 0;
     if (c->fuse_ln) {
         if ((rc = dalloc(c, &c->ln_part, M * (size_t)(D / 64) * 2))) return bail(rc);
         if ((rc = dalloc(c, &c->rowstat, M * 2))) return bail(rc);
