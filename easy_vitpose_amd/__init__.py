@@ -12,10 +12,10 @@ def __getattr__(name):
     if name == 'VitInference':
         from .inference import VitInference
         return VitInference
-    if name in ('VitPoseHip', 'decode_heatmaps'):
+    if name in ('VitPoseHip', 'VitPoseGroup', 'PinnedArray', 'decode_heatmaps'):
         from . import engine
         return getattr(engine, name)
     raise AttributeError(name)
 
 
-__all__ = ['VitInference', 'VitPoseHip', 'decode_heatmaps', 'ModelShape', 'model_shape']
+__all__ = ['VitInference', 'VitPoseHip', 'VitPoseGroup', 'PinnedArray', 'decode_heatmaps', 'ModelShape', 'model_shape']

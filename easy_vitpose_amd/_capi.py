@@ -21,7 +21,9 @@ VP_PROF_COUNT = len(VP_PROF_NAMES)
 DTYPES = {'fp16': VP_DTYPE_F16, 'f16': VP_DTYPE_F16, 'bf16': VP_DTYPE_BF16}
 
 # every symbol include/vitpose_hip.h declares (tests check the .so exports all of them)
-SYMBOLS = ['vp_abi_version', 'vp_create', 'vp_load_weights', 'vp_infer', 'vp_infer_device', 'vp_infer_frame', 'vp_infer_flip', 'vp_infer_heatmaps',
+SYMBOLS = ['vp_abi_version', 'vp_create', 'vp_load_weights', 'vp_infer', 'vp_infer_device', 'vp_infer_device_stream', 'vp_host_alloc', 'vp_host_free',
+           'vp_infer_submit', 'vp_infer_wait', 'vp_group_create', 'vp_group_size', 'vp_group_member', 'vp_group_load_weights', 'vp_group_infer',
+           'vp_group_infer_allgather', 'vp_group_destroy', 'vp_group_last_error', 'vp_infer_frame', 'vp_infer_flip', 'vp_infer_heatmaps',
            'vp_infer_tokens', 'vp_decode_only', 'vp_stream', 'vp_synchronize', 'vp_set_profiling',
            'vp_reset_profile', 'vp_get_profile', 'vp_destroy', 'vp_last_error',
            'vp_dbg_gemm', 'vp_dbg_attention', 'vp_dbg_layernorm', 'vp_dbg_deconv', 'vp_dbg_gemm_bench', 'vp_dbg_gemm_bench2', 'vp_dbg_gemm_compare', 'vp_dbg_gemm8_timeline', 'vp_dbg_gemm_timeline', 'vp_dbg_peak', 'vp_dbg_crop_prep']
@@ -76,6 +78,23 @@ def load_library():
     lib.vp_load_weights.argtypes = [H, C.POINTER(vp_tensor_desc), C.c_int32]
     lib.vp_infer.argtypes = [H, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
     lib.vp_infer_device.argtypes = [H, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32]
+    lib.vp_infer_device_stream.argtypes = [H, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.vp_host_alloc.argtypes = [C.c_size_t]
+    lib.vp_host_alloc.restype = C.c_void_p
+    lib.vp_host_free.argtypes = [C.c_void_p]
+    lib.vp_host_free.restype = None
+    lib.vp_infer_submit.argtypes = [H, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.POINTER(C.c_int32)]
+    lib.vp_infer_wait.argtypes = [H, C.c_int32]
+    lib.vp_group_create.argtypes = [C.POINTER(H), C.POINTER(vp_config), C.POINTER(C.c_int32), C.c_int32]
+    lib.vp_group_size.argtypes = [H]
+    lib.vp_group_member.argtypes = [H, C.c_int32]
+    lib.vp_group_member.restype = C.c_void_p
+    lib.vp_group_load_weights.argtypes = [H, C.POINTER(vp_tensor_desc), C.c_int32]
+    lib.vp_group_infer.argtypes = [H, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
+    lib.vp_group_infer_allgather.argtypes = [H, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.POINTER(C.c_void_p), C.c_void_p]
+    lib.vp_group_destroy.argtypes = [H]
+    lib.vp_group_last_error.argtypes = [H]
+    lib.vp_group_last_error.restype = C.c_char_p
     lib.vp_infer_frame.argtypes = [H, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]
     lib.vp_dbg_crop_prep.argtypes = [C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]
     lib.vp_infer_heatmaps.argtypes = [H, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
@@ -103,7 +122,7 @@ def load_library():
     lib.vp_dbg_gemm_timeline.argtypes = [C.c_int32] * 6 + [C.POINTER(C.c_uint64), C.c_int32]
     lib.vp_dbg_peak.argtypes = [C.c_int32, C.c_int32, C.POINTER(C.c_double)]
     for name in SYMBOLS:
-        if name not in ('vp_stream', 'vp_last_error'):
+        if name not in ('vp_stream', 'vp_last_error', 'vp_host_alloc', 'vp_host_free', 'vp_group_member', 'vp_group_last_error'):
             getattr(lib, name).restype = C.c_int
     _lib = lib
     return lib

@@ -69,6 +69,27 @@ template <> __device__ __forceinline__ f32x4 mfma16<BF16>(u32x4 a, u32x4 b, f32x
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
+// Two-plane residual stream: x = hi + lo with hi = round16(x), lo = round16(x - hi).  fp16: x is clamped to the fp16 range FIRST
+// (+-65504), so hi cannot saturate away from x and lo stays a tiny correction (an unclamped |x| > 65504 would leave
+// lo = x - 65504, which the unsaturated lo conversion turns into inf).  Same instruction count as clamping inside the hi conversion.
+template <class T> __device__ __forceinline__ void split_planes2(float& a, float& b, uint32_t& hi, uint32_t& lo);
+template <> __device__ __forceinline__ void split_planes2<F16>(float& a, float& b, uint32_t& hi, uint32_t& lo) {
+    typedef __attribute__((ext_vector_type(2))) _Float16 h2;
+    a = __builtin_amdgcn_fmed3f(a, -65504.f, 65504.f);
+    b = __builtin_amdgcn_fmed3f(b, -65504.f, 65504.f);
+    const h2 h = {(_Float16)a, (_Float16)b};
+    hi = __builtin_bit_cast(uint32_t, h);
+    const h2 l = {(_Float16)(a - (float)h[0]), (_Float16)(b - (float)h[1])};
+    lo = __builtin_bit_cast(uint32_t, l);
+}
+template <> __device__ __forceinline__ void split_planes2<BF16>(float& a, float& b, uint32_t& hi, uint32_t& lo) {
+    typedef __attribute__((ext_vector_type(2))) __bf16 b2;
+    const b2 h = {(__bf16)a, (__bf16)b};
+    hi = __builtin_bit_cast(uint32_t, h);
+    const b2 l = {(__bf16)(a - (float)h[0]), (__bf16)(b - (float)h[1])};
+    lo = __builtin_bit_cast(uint32_t, l);
+}
+
 // LayerNorm folded into a GEMM epilogue: rstd * (acc - mean * s) + b as two explicit fused multiply-adds,
 // so that every kernel that applies it rounds identically (bit-identity between tile configurations is the race screen)
 __device__ __forceinline__ float ln_fold(float acc, float mean, float s, float rstd, float b) {

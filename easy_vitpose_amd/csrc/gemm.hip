@@ -533,11 +533,7 @@ __global__ __launch_bounds__(C::NT, 2) void gemm_kernel(GemmArgs g) {
                     }
                     u32x4 oh, ol;
 #pragma unroll
-                    for (int e = 0; e < 8; e += 2) {   // lo = round16(x - hi) is tiny: no saturation needed
-                        const uint16_t h0 = to_bits<T>(v[e]), h1 = to_bits<T>(v[e + 1]);
-                        oh[e >> 1] = (uint32_t)h0 | ((uint32_t)h1 << 16);
-                        ol[e >> 1] = pack2_nosat<T>(v[e] - from_bits<T>(h0), v[e + 1] - from_bits<T>(h1));
-                    }
+                    for (int e = 0; e < 8; e += 2) { uint32_t h_, l_; split_planes2<T>(v[e], v[e + 1], h_, l_); oh[e >> 1] = h_; ol[e >> 1] = l_; }   // clamps v to the 16-bit range (statistics below see the stored value)
                     if (!(g.ablate & 8)) {
                         *(u32x4*)(out_hi + orow_q[q] + n0 + ch * 8) = oh;
                         *(u32x4*)(out_lo + orow_q[q] + n0 + ch * 8) = ol;
@@ -995,11 +991,13 @@ __global__ __launch_bounds__(C::NT, 2) void gemm_persist_kernel(GemmArgs g) {
 template <class T, int EPI, class C>
 static hipError_t launch_persist(const GemmArgs& a, hipStream_t s) {
     auto kern = gemm_persist_kernel<T, EPI, C>;
-    static bool attr_done = false;
-    if (!attr_done) {
+    static bool attr_done[64] = {};   // the > 64 KiB LDS opt-in is a per-device function attribute
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= 64 || !attr_done[dev]) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
         if (e != hipSuccess) return e;
-        attr_done = true;
+        if (dev >= 0 && dev < 64) attr_done[dev] = true;
     }
     const int tiles = ((a.M + C::BM - 1) / C::BM) * ((a.N + C::BN - 1) / C::BN);
     const int resident = 256 * (160 * 1024 / C::LDS);           // workgroups the chip holds at once
@@ -1040,11 +1038,13 @@ template <class T, int EPI, int AMODE, class C>
 static hipError_t launch(const GemmArgs& a, hipStream_t s) {
     if constexpr ((EPI == EPI_BIAS_RESID_LN || EPI == EPI_POS_LN) && C::DIRECT) return hipErrorInvalidValue;
     auto kern = gemm_kernel<T, EPI, AMODE, C>;
-    static bool attr_done = false;
-    if (!attr_done) {
+    static bool attr_done[64] = {};   // the > 64 KiB LDS opt-in is a per-device function attribute
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= 64 || !attr_done[dev]) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
         if (e != hipSuccess) return e;
-        attr_done = true;
+        if (dev >= 0 && dev < 64) attr_done[dev] = true;
     }
     GemmArgs g = a;
     const int tiles_n = (a.N + C::BN - 1) / C::BN;

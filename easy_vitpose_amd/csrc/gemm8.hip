@@ -362,11 +362,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs g) {
                     }
                     u32x4 oh, ol;
 #pragma unroll
-                    for (int e = 0; e < 8; e += 2) {
-                        const uint16_t h0 = to_bits<T>(v[e]), h1 = to_bits<T>(v[e + 1]);
-                        oh[e >> 1] = (uint32_t)h0 | ((uint32_t)h1 << 16);
-                        ol[e >> 1] = pack2_nosat<T>(v[e] - from_bits<T>(h0), v[e + 1] - from_bits<T>(h1));
-                    }
+                    for (int e = 0; e < 8; e += 2) { uint32_t h_, l_; split_planes2<T>(v[e], v[e + 1], h_, l_); oh[e >> 1] = h_; ol[e >> 1] = l_; }   // clamps v to the 16-bit range (statistics below see the stored value)
                     if (!(g.ablate & 8)) {
                         *(u32x4*)(out_hi + orow_q[q] + n0 + ch * 8) = oh;
                         *(u32x4*)(out_lo + orow_q[q] + n0 + ch * 8) = ol;
@@ -416,7 +412,7 @@ static hipError_t launch8(const GemmArgs& a, hipStream_t s) {
     constexpr int LDS = (EPI == EPI_BIAS_RESID_LN) ? ((128 * (C::BN * 4 + 16) + C::BM * (C::BN / 64) * 8) > C::RING ? (128 * (C::BN * 4 + 16) + C::BM * (C::BN / 64) * 8) : C::RING) : C::RING;
     static bool attr_done[64] = {};   // per device: the LDS opt-in is a per-device function attribute
     int dev = 0;
-    hipGetDevice(&dev);
+    (void)hipGetDevice(&dev);
     if (dev < 0 || dev >= 64 || !attr_done[dev]) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         if (e != hipSuccess) return e;

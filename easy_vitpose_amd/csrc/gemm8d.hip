@@ -306,7 +306,7 @@ static hipError_t launch8_wide(const GemmArgs& a, hipStream_t s) {
     constexpr int LDS = G8<256>::RING + 2 * 4096 + 8 * 1024;
     static bool attr_done[64] = {};
     int dev = 0;
-    hipGetDevice(&dev);
+    (void)hipGetDevice(&dev);
     if (dev < 0 || dev >= 64 || !attr_done[dev]) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         if (e != hipSuccess) return e;

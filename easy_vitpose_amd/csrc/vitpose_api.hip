@@ -89,6 +89,19 @@ struct vp_ctx {
     bool blocked_hid = true;          // mlp hidden activations in the 64x64-blocked layout (VP_BLOCKED_HID=0: row-major)
     bool fuse_ln = true;              // LayerNorm folded into the GEMMs on both sides of it (VP_FUSE_LN=0: standalone passes)
     float *ln_part = nullptr, *rowstat = nullptr;   // partial row statistics [M][D/64][2], (mean, rstd) [M][2]
+    // asynchronous host path (vp_infer_submit / vp_infer_wait): two slots, each with its own device staging, so that the
+    // H2D of call i+1 and the D2H of call i-1 run on the copy stream under the compute of call i
+    struct Slot { void* in = nullptr; int32_t* wh = nullptr; float* kp = nullptr; hipEvent_t h2d = nullptr, done = nullptr, out = nullptr; bool busy = false; };
+    Slot slots[2];
+    hipStream_t copy_stream = nullptr;
+    int next_slot = 0;
+    // small batches: the whole forward + decode of a chunk captured once per (n, input format, source pointer) into a hipGraph and
+    // replayed (170+ launches of a few microseconds each are launch-bound below ~16 crops); VP_GRAPH=0 disables
+    struct GraphEntry { hipGraphExec_t exec = nullptr; int n = 0, fmt = -1, seen = 0; const void* src = nullptr; const int32_t* wh = nullptr; float* out = nullptr; };
+    GraphEntry graphs[4];
+    hipGraphExec_t graph_exec = nullptr;   // (unused placeholder kept for vp_destroy)
+    int graph_max_n = 16;
+    hipEvent_t ev_in = nullptr, ev_out = nullptr;   // vp_infer_device_stream: ordering against the caller's stream
     uint8_t* frame_stage = nullptr;   // device copy of the current video frame (vp_infer_frame)
     size_t frame_cap = 0;
     int32_t* cparams = nullptr;       // per-crop geometry [max_batch, 8]
@@ -459,6 +472,45 @@ int decode_chunk(vp_ctx* c, const int32_t* d_wh, float* d_out, int n) {
     return VP_OK;
 }
 
+// forward + decode of one chunk.  Small chunks (<= graph_max_n crops, profiling off) are launch-bound -- ~110-290 launches of a few
+// microseconds each -- so the second time the same (n, format, buffers) combination is seen the chunk is captured into a hipGraph
+// and from then on replayed with one hipGraphLaunch.
+int run_chunk(vp_ctx* c, const void* d_src, int fmt, int nb, const int32_t* d_wh, float* d_out) {
+    int rc;
+    if (nb > c->graph_max_n || c->prof != 0) {
+        if ((rc = forward_chunk(c, d_src, fmt, nb, false))) return rc;
+        return decode_chunk(c, d_wh, d_out, nb);
+    }
+    vp_ctx::GraphEntry* ge = nullptr;
+    for (auto& g : c->graphs)
+        if (g.n == nb && g.fmt == fmt && g.src == d_src && g.wh == d_wh && g.out == d_out) { ge = &g; break; }
+    if (ge && ge->exec) {
+        HIPCHK(c, hipGraphLaunch(ge->exec, c->stream));
+        return VP_OK;
+    }
+    if (!ge) {   // first sighting: run eagerly (also performs every one-time function-attribute set-up outside a capture), remember the key
+        static int victim = 0;
+        ge = &c->graphs[victim++ & 3];
+        if (ge->exec) { hipGraphExecDestroy(ge->exec); ge->exec = nullptr; }
+        ge->n = nb; ge->fmt = fmt; ge->src = d_src; ge->wh = d_wh; ge->out = d_out; ge->seen = 1;
+        if ((rc = forward_chunk(c, d_src, fmt, nb, false))) return rc;
+        return decode_chunk(c, d_wh, d_out, nb);
+    }
+    // second sighting: capture
+    hipGraph_t graph = nullptr;
+    HIPCHK(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+    rc = forward_chunk(c, d_src, fmt, nb, false);
+    if (!rc) rc = decode_chunk(c, d_wh, d_out, nb);
+    hipError_t e = hipStreamEndCapture(c->stream, &graph);
+    if (rc) { if (graph) hipGraphDestroy(graph); return rc; }
+    if (e != hipSuccess || !graph) return fail(c, VP_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
+    e = hipGraphInstantiate(&ge->exec, graph, nullptr, nullptr, 0);
+    hipGraphDestroy(graph);
+    if (e != hipSuccess) { ge->exec = nullptr; return fail(c, VP_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e)); }
+    HIPCHK(c, hipGraphLaunch(ge->exec, c->stream));
+    return VP_OK;
+}
+
 size_t crop_bytes(int fmt) { return (size_t)3 * 256 * 192 * (fmt == VP_INPUT_F32_NCHW ? 4 : 1); }
 
 int check_ready(vp_ctx* c, int fmt, int n, const void* p0, const void* p1) {
@@ -476,6 +528,7 @@ int check_ready(vp_ctx* c, int fmt, int n, const void* p0, const void* p1) {
 extern "C" {
 
 int vp_abi_version(void) { return VP_ABI_VERSION; }
+int vp_group_destroy(vp_group_handle g);
 
 int vp_create(vp_handle* out, const vp_config* cfg) {
     if (!out || !cfg) return fail(nullptr, VP_ERR_INVALID, "null argument");
@@ -517,6 +570,7 @@ int vp_create(vp_handle* out, const vp_config* cfg) {
     if (const char* f = getenv("VP_PERSIST")) c->persist_gemm = atoi(f) != 0;
     if (const char* f = getenv("VP_GEMM8")) c->gemm8_mask = atoi(f);
     if (const char* f = getenv("VP_G8_STAGGER")) c->g8_stagger = atoi(f);
+    if (const char* f = getenv("VP_GRAPH")) c->graph_max_n = atoi(f) != 0 ? 16 : 0;
     if (const char* f = getenv("VP_G8_DEFERRED")) c->g8_deferred = atoi(f) != 0;
     if (c->fuse_ln) {
         if ((rc = dalloc(c, &c->ln_part, M * (size_t)(D / 64) * 2))) return bail(rc);
@@ -604,10 +658,25 @@ int vp_infer_device(vp_handle c, const void* d_crops, int32_t fmt, int32_t n, co
     for (int off = 0; off < n; off += c->maxb) {
         const int nb = (n - off < c->maxb) ? n - off : c->maxb;
         const char* src = (const char*)d_crops + (size_t)off * crop_bytes(fmt);
-        if ((rc = forward_chunk(c, src, fmt, nb, false))) return rc;
-        if ((rc = decode_chunk(c, d_org_wh ? d_org_wh + 2 * (size_t)off : nullptr, d_out + (size_t)off * c->Kp * 3, nb))) return rc;
+        if ((rc = run_chunk(c, src, fmt, nb, d_org_wh ? d_org_wh + 2 * (size_t)off : nullptr, d_out + (size_t)off * c->Kp * 3))) return rc;
     }
     if (sync) HIPCHK(c, hipStreamSynchronize(c->stream));
+    return VP_OK;
+}
+
+int vp_infer_device_stream(vp_handle c, const void* d_crops, int32_t fmt, int32_t n, const int32_t* d_org_wh, float* d_out, void* caller_stream) {
+    int rc = check_ready(c, fmt, n, d_crops, d_out);
+    if (rc) return rc;
+    hipStream_t cs = (hipStream_t)caller_stream;
+    if (!c->ev_in) HIPCHK(c, hipEventCreateWithFlags(&c->ev_in, hipEventDisableTiming));
+    if (!c->ev_out) HIPCHK(c, hipEventCreateWithFlags(&c->ev_out, hipEventDisableTiming));
+    // everything the caller enqueued on its stream so far (the producers of d_crops / d_org_wh) happens before the library's kernels ...
+    HIPCHK(c, hipEventRecord(c->ev_in, cs));
+    HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_in, 0));
+    if ((rc = vp_infer_device(c, d_crops, fmt, n, d_org_wh, d_out, 0))) return rc;
+    // ... and whatever the caller enqueues afterwards (consumers of d_out) happens after them
+    HIPCHK(c, hipEventRecord(c->ev_out, c->stream));
+    HIPCHK(c, hipStreamWaitEvent(cs, c->ev_out, 0));
     return VP_OK;
 }
 
@@ -619,11 +688,64 @@ int vp_infer(vp_handle c, const void* crops, int32_t fmt, int32_t n, const int32
         const char* src = (const char*)crops + (size_t)off * crop_bytes(fmt);
         HIPCHK(c, hipMemcpyAsync(c->in_stage, src, (size_t)nb * crop_bytes(fmt), hipMemcpyHostToDevice, c->stream));
         if (org_wh) HIPCHK(c, hipMemcpyAsync(c->wh_stage, org_wh + 2 * (size_t)off, (size_t)nb * 8, hipMemcpyHostToDevice, c->stream));
-        if ((rc = forward_chunk(c, c->in_stage, fmt, nb, false))) return rc;
-        if ((rc = decode_chunk(c, org_wh ? c->wh_stage : nullptr, c->kp, nb))) return rc;
+        if ((rc = run_chunk(c, c->in_stage, fmt, nb, org_wh ? c->wh_stage : nullptr, c->kp))) return rc;
         HIPCHK(c, hipMemcpyAsync(out + (size_t)off * c->Kp * 3, c->kp, (size_t)nb * c->Kp * 12, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
     }
+    return VP_OK;
+}
+
+// ---- asynchronous host path ----------------------------------------------------------------------------------------------
+void* vp_host_alloc(size_t bytes) {
+    void* p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) return nullptr;
+    return p;
+}
+void vp_host_free(void* p) { if (p) hipHostFree(p); }
+
+int vp_infer_submit(vp_handle c, const void* crops, int32_t fmt, int32_t n, const int32_t* org_wh, float* out, int32_t* slot_out) {
+    int rc = check_ready(c, fmt, n, crops, out);
+    if (rc) return rc;
+    if (!slot_out) return fail(c, VP_ERR_INVALID, "null slot pointer");
+    if (n <= 0 || n > c->maxb) return fail(c, VP_ERR_INVALID, "vp_infer_submit takes 1 .. max_batch crops per call");
+    if (!c->copy_stream) HIPCHK(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+    const int si = c->next_slot;
+    vp_ctx::Slot& sl = c->slots[si];
+    if (sl.busy) return fail(c, VP_ERR_STATE, "both slots in flight: call vp_infer_wait first");
+    if (!sl.in) {
+        char* q;
+        if ((rc = dalloc(c, &q, (size_t)c->maxb * crop_bytes(VP_INPUT_F32_NCHW)))) return rc;
+        sl.in = q;
+        if ((rc = dalloc(c, &sl.wh, (size_t)c->maxb * 2)) || (rc = dalloc(c, &sl.kp, (size_t)c->maxb * c->Kp * 3))) return rc;
+        HIPCHK(c, hipEventCreateWithFlags(&sl.h2d, hipEventDisableTiming));
+        HIPCHK(c, hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+        HIPCHK(c, hipEventCreateWithFlags(&sl.out, hipEventDisableTiming));
+    }
+    // copy stream: H2D of this call (the slot's previous D2H finished: vp_infer_wait was called on it)
+    HIPCHK(c, hipMemcpyAsync(sl.in, crops, (size_t)n * crop_bytes(fmt), hipMemcpyHostToDevice, c->copy_stream));
+    if (org_wh) HIPCHK(c, hipMemcpyAsync(sl.wh, org_wh, (size_t)n * 8, hipMemcpyHostToDevice, c->copy_stream));
+    HIPCHK(c, hipEventRecord(sl.h2d, c->copy_stream));
+    // compute stream: after the upload
+    HIPCHK(c, hipStreamWaitEvent(c->stream, sl.h2d, 0));
+    if ((rc = run_chunk(c, sl.in, fmt, n, org_wh ? sl.wh : nullptr, sl.kp))) return rc;
+    HIPCHK(c, hipEventRecord(sl.done, c->stream));
+    // copy stream: D2H of the keypoints after the compute
+    HIPCHK(c, hipStreamWaitEvent(c->copy_stream, sl.done, 0));
+    HIPCHK(c, hipMemcpyAsync(out, sl.kp, (size_t)n * c->Kp * 12, hipMemcpyDeviceToHost, c->copy_stream));
+    HIPCHK(c, hipEventRecord(sl.out, c->copy_stream));
+    sl.busy = true;
+    *slot_out = si;
+    c->next_slot = si ^ 1;
+    return VP_OK;
+}
+
+int vp_infer_wait(vp_handle c, int32_t slot) {
+    if (!c || slot < 0 || slot > 1) return VP_ERR_INVALID;
+    vp_ctx::Slot& sl = c->slots[slot];
+    if (!sl.busy) return fail(c, VP_ERR_STATE, "slot not in flight");
+    HIPCHK(c, hipSetDevice(c->cfg.device_id));
+    HIPCHK(c, hipEventSynchronize(sl.out));
+    sl.busy = false;
     return VP_OK;
 }
 
@@ -632,6 +754,7 @@ int vp_infer_flip(vp_handle c, const void* crops, int32_t fmt, int32_t n, const 
     int rc = check_ready(c, fmt, n, crops, out ? (const void*)out : (const void*)heatmaps);
     if (rc) return rc;
     if (n_pairs < 0 || (n_pairs > 0 && !flip_pairs)) return fail(c, VP_ERR_INVALID, "bad flip_pairs");
+    if (n == 0) return VP_OK;   // nothing to do (and no async upload of the stack-lifetime partner table left in flight)
     std::vector<int32_t> partner(c->Kp);
     for (int k = 0; k < c->Kp; ++k) partner[k] = k;
     for (int i = 0; i < n_pairs; ++i) {
@@ -643,7 +766,7 @@ int vp_infer_flip(vp_handle c, const void* crops, int32_t fmt, int32_t n, const 
     const size_t hm_elems = (size_t)c->maxb * c->Kp * 3072;
     if (!c->hm_keep && (rc = dalloc(c, &c->hm_keep, hm_elems))) return rc;
     if (!c->partner && (rc = dalloc(c, &c->partner, (size_t)c->Kp))) return rc;
-    HIPCHK(c, hipMemcpyAsync(c->partner, partner.data(), (size_t)c->Kp * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpy(c->partner, partner.data(), (size_t)c->Kp * 4, hipMemcpyHostToDevice));   // synchronous: `partner` is a local
     for (int off = 0; off < n; off += c->maxb) {
         const int nb = (n - off < c->maxb) ? n - off : c->maxb;
         const char* src = (const char*)crops + (size_t)off * crop_bytes(fmt);
@@ -698,8 +821,14 @@ int vp_infer_frame(vp_handle c, const uint8_t* frame, int32_t fh, int32_t fw, co
     const size_t fbytes = (size_t)fh * fw * 3;
     if (fbytes > c->frame_cap) {
         void* q = nullptr;
+        HIPCHK(c, hipStreamSynchronize(c->stream));
         HIPCHK(c, hipMalloc(&q, fbytes + 256));
-        c->allocs.push_back(q);      // the old (smaller) staging buffer is released with the handle
+        if (c->frame_stage) {        // release the smaller staging buffer now: growing resolutions must not grow device memory
+            for (auto it = c->allocs.begin(); it != c->allocs.end(); ++it)
+                if (*it == (void*)c->frame_stage) { c->allocs.erase(it); break; }
+            hipFree(c->frame_stage);
+        }
+        c->allocs.push_back(q);
         c->frame_stage = (uint8_t*)q;
         c->frame_cap = fbytes;
     }
@@ -721,8 +850,7 @@ int vp_infer_frame(vp_handle c, const uint8_t* frame, int32_t fh, int32_t fw, co
         for (int i = 0; i < nb; ++i) { wh[2 * i] = crop_params[8 * (size_t)(off + i) + 6]; wh[2 * i + 1] = crop_params[8 * (size_t)(off + i) + 7]; }
         HIPCHK(c, hipMemcpyAsync(c->wh_stage, wh.data(), (size_t)nb * 8, hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));   // wh is a stack-lifetime host buffer
-        if ((rc = forward_chunk(c, c->in_stage, VP_INPUT_U8_NHWC, nb, false))) return rc;
-        if ((rc = decode_chunk(c, c->wh_stage, c->kp, nb))) return rc;
+        if ((rc = run_chunk(c, c->in_stage, VP_INPUT_U8_NHWC, nb, c->wh_stage, c->kp))) return rc;
         HIPCHK(c, hipMemcpyAsync(out + (size_t)off * c->Kp * 3, c->kp, (size_t)nb * c->Kp * 12, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
     }
@@ -739,10 +867,10 @@ int vp_decode_only(int32_t device_id, const float* heatmaps, int32_t n, int32_t 
     float *d_hm = nullptr, *d_out = nullptr;
     int32_t* d_wh = nullptr;
     const size_t hb = (size_t)n * k * 3072 * 4, ob = (size_t)n * k * 12;
-    HIPCHK(c, hipMalloc((void**)&d_hm, hb));
-    HIPCHK(c, hipMalloc((void**)&d_out, ob));
     int rc = VP_OK;
-    hipError_t e = hipMemcpy(d_hm, heatmaps, hb, hipMemcpyHostToDevice);
+    hipError_t e = hipMalloc((void**)&d_hm, hb);
+    if (e == hipSuccess) e = hipMalloc((void**)&d_out, ob);
+    if (e == hipSuccess) e = hipMemcpy(d_hm, heatmaps, hb, hipMemcpyHostToDevice);
     if (e == hipSuccess && org_wh) {
         e = hipMalloc((void**)&d_wh, (size_t)n * 8);
         if (e == hipSuccess) e = hipMemcpy(d_wh, org_wh, (size_t)n * 8, hipMemcpyHostToDevice);
@@ -751,9 +879,124 @@ int vp_decode_only(int32_t device_id, const float* heatmaps, int32_t n, int32_t 
     if (e == hipSuccess) e = hipDeviceSynchronize();
     if (e == hipSuccess) e = hipMemcpy(out, d_out, ob, hipMemcpyDeviceToHost);
     if (e != hipSuccess) rc = fail(nullptr, VP_ERR_HIP, std::string("vp_decode_only: ") + hipGetErrorString(e));
-    hipFree(d_hm); hipFree(d_out); if (d_wh) hipFree(d_wh);
+    if (d_hm) hipFree(d_hm);
+    if (d_out) hipFree(d_out);
+    if (d_wh) hipFree(d_wh);
     return rc;
 }
+
+// ---- multi-GPU group (one process, N devices): crops sharded contiguously, weights replicated ------------------------------
+struct vp_group {
+    std::vector<vp_ctx*> h;
+    std::vector<float*> d_all;   // per device: [max_total, K, 3] keypoints of EVERY shard (vp_group_infer_allgather)
+    size_t all_cap = 0;
+    std::string err;
+};
+namespace { thread_local std::string g_group_error; }
+
+int vp_group_create(vp_group_handle* out, const vp_config* cfg, const int32_t* device_ids, int32_t n_devices) {
+    if (!out || !cfg || !device_ids || n_devices <= 0) { g_group_error = "null argument"; return VP_ERR_INVALID; }
+    *out = nullptr;
+    vp_group* g = new vp_group();
+    for (int i = 0; i < n_devices; ++i) {
+        vp_config c = *cfg;
+        c.device_id = device_ids[i];
+        vp_handle h = nullptr;
+        int rc = vp_create(&h, &c);
+        if (rc) { g_group_error = std::string("device ") + std::to_string(device_ids[i]) + ": " + vp_last_error(nullptr); vp_group_destroy(g); return rc; }
+        g->h.push_back(h);
+    }
+    // peer access for the device-side all-gather (xGMI links are point to point: one copy per pair)
+    for (int i = 0; i < n_devices; ++i)
+        for (int j = 0; j < n_devices; ++j)
+            if (i != j) {
+                hipSetDevice(device_ids[i]);
+                int can = 0;
+                if (hipDeviceCanAccessPeer(&can, device_ids[i], device_ids[j]) == hipSuccess && can) {
+                    hipError_t e = hipDeviceEnablePeerAccess(device_ids[j], 0);
+                    if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();
+                }
+            }
+    *out = g;
+    return VP_OK;
+}
+
+int vp_group_size(vp_group_handle g) { return g ? (int)g->h.size() : 0; }
+
+int vp_group_load_weights(vp_group_handle g, const vp_tensor_desc* tensors, int32_t n_tensors) {
+    if (!g) return VP_ERR_INVALID;
+    for (auto* h : g->h) {
+        int rc = vp_load_weights(h, tensors, n_tensors);
+        if (rc) { g->err = h->err; return rc; }
+    }
+    return VP_OK;
+}
+
+// shard i of n crops over w devices: [off, off + cnt), contiguous, ceil(n / w) per device (the last ones may be short or empty)
+static void group_shard(int n, int w, int i, int& off, int& cnt) {
+    const int per = (n + w - 1) / w;
+    off = per * i < n ? per * i : n;
+    cnt = n - off < per ? n - off : per;
+}
+
+static int group_run(vp_group* g, const void* crops, int32_t fmt, int32_t n, const int32_t* org_wh, float* out, float* const* d_all) {
+    if (!g || n < 0 || (n > 0 && (!crops || (!out && !d_all)))) return VP_ERR_INVALID;
+    const int w = (int)g->h.size();
+    const int K = g->h[0]->Kp;
+    std::vector<float> scratch;
+    if (!out) { scratch.resize((size_t)n * K * 3); out = scratch.data(); }
+    // rounds of (devices x max_batch) crops; inside a round every device works on its shard concurrently (asynchronous submit)
+    const int per_round = w * g->h[0]->maxb;
+    for (int r0 = 0; r0 < n; r0 += per_round) {
+        const int nr = n - r0 < per_round ? n - r0 : per_round;
+        std::vector<int> slot(w, -1), offs(w, 0), cnts(w, 0);
+        for (int i = 0; i < w; ++i) {
+            int off, cnt;
+            group_shard(nr, w, i, off, cnt);
+            offs[i] = r0 + off; cnts[i] = cnt;
+            if (cnt <= 0) continue;
+            int rc = vp_infer_submit(g->h[i], (const char*)crops + (size_t)offs[i] * crop_bytes(fmt), fmt, cnt,
+                                     org_wh ? org_wh + 2 * (size_t)offs[i] : nullptr, out + (size_t)offs[i] * K * 3, &slot[i]);
+            if (rc) { g->err = g->h[i]->err; return rc; }
+            if (d_all) {   // all-gather on the device side: this shard's keypoints to every device's copy, peer to peer, on the owner's stream
+                vp_ctx* c = g->h[i];
+                for (int j = 0; j < w; ++j) {
+                    hipError_t e = hipMemcpyPeerAsync(d_all[j] + (size_t)offs[i] * K * 3, g->h[j]->cfg.device_id, c->slots[slot[i]].kp,
+                                                      c->cfg.device_id, (size_t)cnt * K * 12, c->stream);
+                    if (e != hipSuccess) { g->err = std::string("hipMemcpyPeerAsync: ") + hipGetErrorString(e); return VP_ERR_HIP; }
+                }
+            }
+        }
+        for (int i = 0; i < w; ++i)
+            if (slot[i] >= 0) {
+                int rc = vp_infer_wait(g->h[i], slot[i]);
+                if (!rc && d_all) rc = vp_synchronize(g->h[i]);
+                if (rc) { g->err = g->h[i]->err; return rc; }
+            }
+    }
+    return VP_OK;
+}
+
+int vp_group_infer(vp_group_handle g, const void* crops, int32_t fmt, int32_t n, const int32_t* org_wh, float* out) {
+    if (!out && n > 0) return VP_ERR_INVALID;
+    return group_run(g, crops, fmt, n, org_wh, out, nullptr);
+}
+
+int vp_group_infer_allgather(vp_group_handle g, const void* crops, int32_t fmt, int32_t n, const int32_t* org_wh, float* const* d_all, float* out) {
+    if (!g || !d_all) return VP_ERR_INVALID;
+    return group_run(g, crops, fmt, n, org_wh, out, d_all);
+}
+
+vp_handle vp_group_member(vp_group_handle g, int32_t i) { return (g && i >= 0 && i < (int)g->h.size()) ? g->h[i] : nullptr; }
+
+int vp_group_destroy(vp_group_handle g) {
+    if (!g) return VP_OK;
+    for (auto* h : g->h) vp_destroy(h);
+    delete g;
+    return VP_OK;
+}
+
+const char* vp_group_last_error(vp_group_handle g) { return g ? g->err.c_str() : g_group_error.c_str(); }
 
 void* vp_stream(vp_handle c) { return c ? (void*)c->stream : nullptr; }
 
@@ -792,7 +1035,12 @@ int vp_destroy(vp_handle c) {
     if (c->stream) hipStreamSynchronize(c->stream);
     for (auto& e : c->evs) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
     for (auto& p : c->ev_pool) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
+    for (auto& sl : c->slots) { if (sl.h2d) hipEventDestroy(sl.h2d); if (sl.done) hipEventDestroy(sl.done); if (sl.out) hipEventDestroy(sl.out); }
+    if (c->ev_in) hipEventDestroy(c->ev_in);
+    if (c->ev_out) hipEventDestroy(c->ev_out);
+    for (auto& ge : c->graphs) if (ge.exec) hipGraphExecDestroy(ge.exec);
     for (void* p : c->allocs) hipFree(p);
+    if (c->copy_stream) { hipStreamSynchronize(c->copy_stream); hipStreamDestroy(c->copy_stream); }
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
     return VP_OK;

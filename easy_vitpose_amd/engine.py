@@ -14,9 +14,47 @@ from .configs import HM_H, HM_W, IMG_H, IMG_W, ModelShape
 
 
 def _as_f32_numpy(v) -> np.ndarray:
-    if hasattr(v, 'detach'):  # torch tensor
-        v = v.detach().cpu().numpy()
+    if hasattr(v, 'detach'):  # torch tensor (bf16 / fp16 checkpoints have no numpy dtype: widen first)
+        v = v.detach().float().cpu().numpy()
     return np.ascontiguousarray(np.asarray(v), dtype=np.float32)
+
+
+def _tensor_descs(state_dict):
+    """state dict -> (ctypes array of vp_tensor_desc, list keeping the float32 arrays alive)"""
+    sd = state_dict['state_dict'] if 'state_dict' in state_dict else state_dict  # inference.py:163-166
+    keep, descs = [], []
+    for name, v in sd.items():
+        if name.endswith('num_batches_tracked'):
+            continue
+        a = _as_f32_numpy(v)
+        keep.append(a)
+        descs.append(capi.vp_tensor_desc(name.encode(), a.ctypes.data_as(C.POINTER(C.c_float)), a.size))
+    return (capi.vp_tensor_desc * len(descs))(*descs), keep
+
+
+class PinnedArray:
+    """numpy view of page-locked host memory (vp_host_alloc): the buffers vp_infer_submit can copy from / to asynchronously."""
+
+    def __init__(self, shape, dtype):
+        self._lib = capi.load_library()
+        n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        self._ptr = self._lib.vp_host_alloc(max(n, 1))
+        if not self._ptr:
+            raise MemoryError(f'vp_host_alloc({n}) failed')
+        buf = (C.c_char * max(n, 1)).from_address(self._ptr)
+        self.array = np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+
+    def free(self):
+        if getattr(self, '_ptr', None):
+            self.array = None
+            self._lib.vp_host_free(self._ptr)
+            self._ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
 
 
 class VitPoseHip:
@@ -42,16 +80,8 @@ class VitPoseHip:
 
     # -------------------------------------------------------------- weights
     def _load(self, state_dict):
-        sd = state_dict['state_dict'] if 'state_dict' in state_dict else state_dict  # inference.py:163-166
-        keep, descs = [], []
-        for name, v in sd.items():
-            if name.endswith('num_batches_tracked'):
-                continue
-            a = _as_f32_numpy(v)
-            keep.append(a)
-            descs.append(capi.vp_tensor_desc(name.encode(), a.ctypes.data_as(C.POINTER(C.c_float)), a.size))
-        arr = (capi.vp_tensor_desc * len(descs))(*descs)
-        code = self.lib.vp_load_weights(self._h, arr, len(descs))
+        arr, keep = _tensor_descs(state_dict)
+        code = self.lib.vp_load_weights(self._h, arr, len(arr))
         if code == capi.VP_ERR_MISSING_TENSOR:
             raise KeyError(capi.last_error(self._h))      # load_state_dict's "Missing key(s)"
         if code == capi.VP_ERR_SHAPE:
@@ -82,8 +112,11 @@ class VitPoseHip:
                                      None if wh is None else wh.ctypes.data, out.ctypes.data), self._h)
         return out
 
-    def infer_device(self, d_crops, d_out, org_wh=None, sync: bool = True):
-        """Device-resident torch tensors in/out (no copies); enqueued on the library's stream."""
+    def infer_device(self, d_crops, d_out, org_wh=None, sync: bool = True, ordered: bool = True):
+        """Device-resident torch tensors in/out (no copies).  The kernels run on the library's own stream; with `ordered`
+        (default) they are ordered after everything already enqueued on torch's CURRENT stream (the producers of `d_crops`)
+        and torch work enqueued afterwards waits for them (vp_infer_device_stream) -- `d_out` can be consumed by the next
+        torch op without a host synchronisation.  `sync` additionally blocks the host until the result is complete."""
         import torch
         assert d_crops.is_cuda and d_out.is_cuda and d_crops.is_contiguous() and d_out.is_contiguous()
         fmt = capi.VP_INPUT_U8_NHWC if d_crops.dtype == torch.uint8 else capi.VP_INPUT_F32_NCHW
@@ -93,8 +126,33 @@ class VitPoseHip:
         if org_wh is not None:
             assert org_wh.is_cuda and org_wh.dtype == torch.int32 and org_wh.numel() == 2 * n
             whp = org_wh.data_ptr()
-        capi.check(self.lib.vp_infer_device(self._h, d_crops.data_ptr(), fmt, n, whp, d_out.data_ptr(), int(sync)), self._h)
+        if ordered:
+            cs = torch.cuda.current_stream(d_crops.device).cuda_stream
+            capi.check(self.lib.vp_infer_device_stream(self._h, d_crops.data_ptr(), fmt, n, whp, d_out.data_ptr(), cs), self._h)
+            if sync:
+                self.synchronize()
+        else:
+            capi.check(self.lib.vp_infer_device(self._h, d_crops.data_ptr(), fmt, n, whp, d_out.data_ptr(), int(sync)), self._h)
         return d_out
+
+    def submit(self, crops: np.ndarray, out: np.ndarray, org_wh=None) -> int:
+        """Asynchronous host path (vp_infer_submit): enqueue one batch (<= max_batch crops) and return its slot; `crops`,
+        `org_wh` and `out` must stay alive and untouched until `wait(slot)`.  Pinned buffers (PinnedArray) make the copies
+        overlap the previous batch's compute; two batches may be in flight."""
+        assert crops.flags['C_CONTIGUOUS'] and out.flags['C_CONTIGUOUS'] and out.dtype == np.float32
+        n = crops.shape[0]
+        assert out.size == n * self.K * 3
+        wh = None if org_wh is None else np.ascontiguousarray(org_wh, dtype=np.int32).reshape(n, 2)
+        self._inflight_wh = getattr(self, '_inflight_wh', {})
+        slot = C.c_int32(-1)
+        capi.check(self.lib.vp_infer_submit(self._h, crops.ctypes.data, self._fmt(crops), n, None if wh is None else wh.ctypes.data,
+                                            out.ctypes.data, C.byref(slot)), self._h)
+        self._inflight_wh[slot.value] = (crops, wh, out)
+        return slot.value
+
+    def wait(self, slot: int):
+        capi.check(self.lib.vp_infer_wait(self._h, int(slot)), self._h)
+        getattr(self, '_inflight_wh', {}).pop(int(slot), None)
 
     def infer_flip(self, crops: np.ndarray, flip_pairs, org_wh=None, shift_heatmap: bool = False, return_heatmaps: bool = False):
         """Flip-test inference (reference head `inference_model(x, flip_pairs)` + `flip_back`, topdown_heatmap_simple_head.py:
@@ -198,3 +256,59 @@ def crop_prep_device(frame: np.ndarray, params: np.ndarray, device_id: int = 0) 
     capi.check(lib.vp_dbg_crop_prep(device_id, frame.ctypes.data, frame.shape[0], frame.shape[1], params.ctypes.data,
                                     len(params), out.ctypes.data))
     return out
+
+
+class VitPoseGroup:
+    """One process, N GPUs (vp_group_*): weights replicated, crops of a call sharded contiguously, all devices concurrent."""
+
+    def __init__(self, shape: ModelShape, state_dict, device_ids, dtype: str = 'fp16', max_batch: int = 64):
+        self.lib = capi.load_library()
+        self.shape, self.K = shape, shape.num_keypoints
+        self.device_ids = [int(d) for d in device_ids]
+        cfg = capi.vp_config(shape.embed_dim, shape.depth, shape.num_heads, shape.num_keypoints, capi.DTYPES[dtype], 0, int(max_batch))
+        ids = (C.c_int32 * len(self.device_ids))(*self.device_ids)
+        g = C.c_void_p()
+        code = self.lib.vp_group_create(C.byref(g), C.byref(cfg), ids, len(self.device_ids))
+        if code != capi.VP_OK:
+            raise capi.VpError(code, (self.lib.vp_group_last_error(None) or b'').decode('utf-8', 'replace'))
+        self._g = g
+        arr, keep = _tensor_descs(state_dict)
+        self._check(self.lib.vp_group_load_weights(self._g, arr, len(arr)))
+
+    def _check(self, code):
+        if code != capi.VP_OK:
+            raise capi.VpError(code, (self.lib.vp_group_last_error(self._g) or b'').decode('utf-8', 'replace'))
+
+    def infer(self, crops: np.ndarray, org_wh=None) -> np.ndarray:
+        crops = np.ascontiguousarray(crops)
+        n = crops.shape[0]
+        out = np.empty((n, self.K, 3), dtype=np.float32)
+        if n == 0:
+            return out
+        wh = None if org_wh is None else np.ascontiguousarray(org_wh, dtype=np.int32).reshape(n, 2)
+        self._check(self.lib.vp_group_infer(self._g, crops.ctypes.data, VitPoseHip._fmt(crops), n,
+                                            None if wh is None else wh.ctypes.data, out.ctypes.data))
+        return out
+
+    def infer_allgather(self, crops: np.ndarray, d_all, org_wh=None):
+        """`d_all`: one torch float32 tensor [n, K, 3] per device of the group; every one receives ALL keypoints (peer copies)."""
+        crops = np.ascontiguousarray(crops)
+        n = crops.shape[0]
+        assert len(d_all) == len(self.device_ids) and all(t.is_cuda and t.is_contiguous() and t.numel() == n * self.K * 3 for t in d_all)
+        ptrs = (C.c_void_p * len(d_all))(*[t.data_ptr() for t in d_all])
+        out = np.empty((n, self.K, 3), dtype=np.float32)
+        wh = None if org_wh is None else np.ascontiguousarray(org_wh, dtype=np.int32).reshape(n, 2)
+        self._check(self.lib.vp_group_infer_allgather(self._g, crops.ctypes.data, VitPoseHip._fmt(crops), n,
+                                                      None if wh is None else wh.ctypes.data, ptrs, out.ctypes.data))
+        return out
+
+    def close(self):
+        if getattr(self, '_g', None):
+            self.lib.vp_group_destroy(self._g)
+            self._g = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

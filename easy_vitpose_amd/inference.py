@@ -133,7 +133,8 @@ class VitInference:
 
     # ----------------------------------------------------------------- glue
     def _call_ultralytics(self, img_rgb):
-        results = self._yolo_model(img_rgb[..., ::-1], verbose=False, imgsz=self.yolo_size, device=0,
+        results = self._yolo_model(img_rgb[..., ::-1], verbose=False, imgsz=self.yolo_size,
+                                   device=self.device if self.device != 'cuda' else 0,   # inference.py:238
                                    classes=self.yolo_classes)[0]
         self._yolo_res = results
         return results.boxes.data.cpu().numpy()[:, :5]

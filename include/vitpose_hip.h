@@ -20,13 +20,14 @@
 #ifndef VITPOSE_HIP_H
 #define VITPOSE_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
 extern "C" {
 #endif
 
-#define VP_ABI_VERSION 1
+#define VP_ABI_VERSION 2
 #define VP_API __attribute__((visibility("default")))
 
 /* status codes (0 = ok).  The Python host maps them onto the exception types the
@@ -52,6 +53,7 @@ enum {
 };
 
 typedef struct vp_ctx* vp_handle;
+typedef struct vp_group* vp_group_handle; /* N handles in one process, one per device (vp_group_*) */
 
 /* Model shape = one row of configs/ViTPose_common.py:65-195 + the dataset's
  * out_channels (configs/ViTPose_<dataset>.py).  Input is fixed at 256x192,
@@ -121,6 +123,42 @@ VP_API int vp_infer(vp_handle h, const void* crops, int32_t input_format, int32_
  * `sync` != 0.  d_org_wh may be NULL. */
 VP_API int vp_infer_device(vp_handle h, const void* d_crops, int32_t input_format, int32_t n,
                     const int32_t* d_org_wh, float* d_out, int32_t sync);
+
+/* vp_infer_device ordered against the CALLER's stream (a hipStream_t, e.g. torch.cuda.current_stream().cuda_stream; NULL =
+ * the legacy default stream): the library's kernels start after everything enqueued on caller_stream so far (the producers
+ * of d_crops / d_org_wh), and work enqueued on caller_stream afterwards (consumers of d_out) starts after them.  Returns
+ * without synchronising.  This is the entry a framework should use; plain vp_infer_device leaves the ordering to the caller. */
+VP_API int vp_infer_device_stream(vp_handle h, const void* d_crops, int32_t input_format, int32_t n,
+                                  const int32_t* d_org_wh, float* d_out, void* caller_stream);
+
+/* Asynchronous host path: the H2D copy of call i+1 and the D2H copy of call i-1 run on a copy stream under the compute of
+ * call i (two slots).  vp_infer_submit enqueues one batch (1 .. max_batch crops) and returns a slot id at once; `crops`,
+ * `org_wh` must stay valid until the upload has happened and `out` until vp_infer_wait(slot) has returned.  For the copies
+ * to be truly asynchronous the host buffers must be pinned: vp_host_alloc / vp_host_free (hipHostMalloc).  At most two
+ * submissions may be in flight. */
+VP_API void* vp_host_alloc(size_t bytes);
+VP_API void vp_host_free(void* p);
+VP_API int vp_infer_submit(vp_handle h, const void* crops, int32_t input_format, int32_t n, const int32_t* org_wh,
+                           float* out, int32_t* slot);
+VP_API int vp_infer_wait(vp_handle h, int32_t slot);
+
+/* Multi-GPU in ONE process (the reference has no inference-side parallelism to mirror, inference.py:167,259-272
+ * -- this is the build's own contract): one handle per device, weights replicated, the crops of a call sharded contiguously
+ * (ceil(n / devices) each), every device running its shard concurrently (asynchronous submit on each handle).
+ * vp_group_infer gathers the keypoints in the host buffer `out` [n, K, 3] (each device's D2H lands in its slice).
+ * vp_group_infer_allgather additionally leaves ALL keypoints on EVERY device: d_all[i] = device buffer [n, K, 3] on device i;
+ * each shard is copied peer to peer (hipMemcpyPeerAsync over the xGMI link of the pair) on its owner's stream -- the
+ * all-gather of north_star without a collective library in the C ABI (the one-process-per-GPU Python host uses RCCL:
+ * easy_vitpose_amd/parallel.py).  `out` may be NULL there.  cfg->device_id is ignored. */
+VP_API int vp_group_create(vp_group_handle* out, const vp_config* cfg, const int32_t* device_ids, int32_t n_devices);
+VP_API int vp_group_size(vp_group_handle g);
+VP_API vp_handle vp_group_member(vp_group_handle g, int32_t i);
+VP_API int vp_group_load_weights(vp_group_handle g, const vp_tensor_desc* tensors, int32_t n_tensors);
+VP_API int vp_group_infer(vp_group_handle g, const void* crops, int32_t input_format, int32_t n, const int32_t* org_wh, float* out);
+VP_API int vp_group_infer_allgather(vp_group_handle g, const void* crops, int32_t input_format, int32_t n, const int32_t* org_wh,
+                                    float* const* d_all, float* out);
+VP_API int vp_group_destroy(vp_group_handle g);
+VP_API const char* vp_group_last_error(vp_group_handle g);
 
 /* Whole-frame entry: the crop loop of VitInference.inference (inference.py:259-266) on device.
  * frame = uint8 RGB [fh, fw, 3] on the host; crop_params = n x 8 int32 {x0, y0, cw, ch, left_pad, top_pad, pw, ph}:

@@ -1,0 +1,134 @@
+"""GPU: the host-facing entries added in round 2 -- stream-ordered device entry, asynchronous host path on pinned buffers,
+hipGraph replay of small batches, the one-process multi-GPU group, ShardedPose over RCCL with the real engine."""
+import os
+
+import numpy as np
+import pytest
+
+from easy_vitpose_amd import PinnedArray, VitPoseGroup, VitPoseHip
+from easy_vitpose_amd.synth import synthetic_crops
+from helpers import weights
+
+pytestmark = pytest.mark.gpu
+
+
+def test_infer_device_is_ordered_after_torch_producers():
+    """vp_infer_device ran on the library's stream with nothing ordering it after torch's stream.  The crops are
+    produced by an asynchronous torch op chain (pinned H2D + arithmetic) right before the call; the result must equal the
+    host-path result, and a torch consumer enqueued right after must see the finished keypoints -- no host synchronisation."""
+    import torch
+    shp, sd, _ = weights('s', 'coco')
+    eng = VitPoseHip(shp, sd, dtype='fp16', max_batch=8)
+    crops = synthetic_crops(8, 3, 'blobs')
+    ref = eng.infer(crops)
+    dev = torch.device('cuda', 0)
+    side = torch.cuda.Stream(device=dev)
+    pinned = torch.from_numpy(crops).pin_memory()
+    for _ in range(5):
+        with torch.cuda.stream(side):
+            junk = torch.empty(64 << 20, dtype=torch.uint8, device=dev).random_()      # keeps the side stream busy first
+            d = pinned.to(dev, non_blocking=True)
+            d = (d.to(torch.int16) + junk[:1].to(torch.int16) * 0).to(torch.uint8)     # produced late on the side stream
+            out = torch.full((8, 17, 3), float('nan'), device=dev)
+            eng.infer_device(d, out, sync=False)                                        # ordered after the producers ...
+            summed = out.sum()                                                          # ... and before this consumer
+        side.synchronize()
+        assert torch.isfinite(summed).item()
+        assert np.array_equal(out.cpu().numpy(), ref)
+    eng.close()
+
+
+def test_async_host_path_matches_sync_path():
+    shp, sd, _ = weights('s', 'coco')
+    eng = VitPoseHip(shp, sd, dtype='fp16', max_batch=16)
+    batches = [synthetic_crops(16, 40 + i, 'noise') for i in range(5)]
+    ref = [eng.infer(b) for b in batches]
+    pin_in = [PinnedArray((16, 256, 192, 3), np.uint8) for _ in range(2)]
+    pin_out = [PinnedArray((16, 17, 3), np.float32) for _ in range(2)]
+    got, pending = [], []
+    for i, b in enumerate(batches):                    # double-buffered: submit i+1 before waiting for i
+        k = i & 1
+        if len(pending) == 2:
+            s, kk = pending.pop(0)
+            eng.wait(s)
+            got.append(pin_out[kk].array.copy())
+        pin_in[k].array[...] = b
+        pending.append((eng.submit(pin_in[k].array, pin_out[k].array), k))
+    for s, kk in pending:
+        eng.wait(s)
+        got.append(pin_out[kk].array.copy())
+    for a, b in zip(got, ref):
+        assert np.array_equal(a, b)
+    with pytest.raises(Exception):                     # a third submission without a wait is refused, not queued silently
+        s0 = eng.submit(pin_in[0].array, pin_out[0].array)
+        s1 = eng.submit(pin_in[1].array, pin_out[1].array)
+        try:
+            eng.submit(pin_in[0].array, pin_out[0].array)
+        finally:
+            eng.wait(s0); eng.wait(s1)
+    eng.close()
+
+
+def test_small_batch_graph_replay_is_bit_identical(monkeypatch):
+    """Batches of <= 16 crops are captured into a hipGraph on their second appearance and replayed afterwards."""
+    shp, sd, _ = weights('s', 'coco')
+    crops = synthetic_crops(8, 5, 'blobs')
+    monkeypatch.setenv('VP_GRAPH', '0')
+    eng = VitPoseHip(shp, sd, dtype='fp16', max_batch=8)
+    ref = eng.infer(crops)
+    eng.close()
+    monkeypatch.setenv('VP_GRAPH', '1')
+    eng = VitPoseHip(shp, sd, dtype='fp16', max_batch=8)
+    outs = [eng.infer(crops) for _ in range(4)]        # eager, capture + launch, replay, replay
+    other = synthetic_crops(8, 6, 'blobs')
+    o2 = eng.infer(other)                              # same graph, new input bytes in the same staging buffer
+    outs.append(eng.infer(crops))
+    eng.close()
+    for o in outs:
+        assert np.array_equal(o, ref)
+    assert not np.array_equal(o2, ref)
+
+
+def test_group_matches_single_handle():
+    """vp_group_* with every visible device (1 on the test box): sharded result == unsharded result, bit for bit; the
+    device-side all-gather leaves all keypoints on every member."""
+    import torch
+    ndev = torch.cuda.device_count()
+    shp, sd, _ = weights('s', 'coco')
+    crops = synthetic_crops(11, 9, 'blobs')
+    one = VitPoseHip(shp, sd, dtype='fp16', max_batch=4)
+    ref = one.infer(crops)
+    one.close()
+    grp = VitPoseGroup(shp, sd, list(range(ndev)), dtype='fp16', max_batch=4)     # 11 crops -> rounds of ndev x 4
+    assert np.array_equal(grp.infer(crops), ref)
+    d_all = [torch.zeros((11, 17, 3), device=f'cuda:{i}') for i in range(ndev)]
+    out = grp.infer_allgather(crops, d_all)
+    assert np.array_equal(out, ref)
+    for t in d_all:
+        assert np.array_equal(t.cpu().numpy(), ref)
+    assert grp.infer(crops[:0]).shape == (0, 17, 3)
+    grp.close()
+
+
+def test_sharded_pose_over_rccl_with_the_real_engine():
+    """ShardedPose (one process per GPU, all-gather over RCCL) with the real engine at the world size the box offers:
+    the gathered result equals the unsharded one bit for bit (crops are independent)."""
+    import torch
+    import torch.distributed as dist
+    from easy_vitpose_amd.parallel import ShardedPose
+    shp, sd, _ = weights('s', 'coco')
+    crops = synthetic_crops(10, 2, 'blobs')
+    eng = VitPoseHip(shp, sd, dtype='fp16', max_batch=16)
+    ref = eng.infer(crops)
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', '29533')
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+    try:
+        sp = ShardedPose(eng.infer, shp.num_keypoints, device='cuda:0')
+        got = sp.infer(crops).cpu().numpy()
+        assert np.array_equal(got, ref)
+        got = sp.infer(crops, pre_sharded=True, n_total=len(crops)).cpu().numpy()   # world 1: the shard is everything
+        assert np.array_equal(got, ref)
+    finally:
+        dist.destroy_process_group()
+        eng.close()
