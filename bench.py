@@ -12,10 +12,10 @@ HBM, + the RCCL all-gather of keypoints when N > 1) over one batch of 256 synthe
 Workload = BASELINE.json configs[1]: ViTPose-B COCO-17, batch 256, seeded random
 weights of that architecture, synthetic uniform-noise crops.
 
-Prints ONE JSON line on rank 0 with `roofline` (dominant kernel symbol = the proj/fc2 residual GEMM,
-timed live with HIP events on the library's stream inside the timed region) and
-`cpu_baseline` (the oracle's torch-CPU per-crop path on this box's host cores, rank 0,
-N=1 only, bounded sample).
+Prints ONE JSON line on rank 0 with `roofline` (the GEMM family with the largest share of the step, timed live
+with HIP events on the library's stream inside the timed region), `step_ms` percentiles, `host_persons_per_sec`
+(N=1: pinned host buffers -> keypoints on the host through the asynchronous double-buffered entry, PCIe included)
+and `cpu_baseline` (the oracle's torch-CPU per-crop path on this box's host cores, rank 0, N=1 only, bounded sample).
 """
 from __future__ import annotations
 
@@ -73,27 +73,73 @@ def cpu_baseline(variant, dataset, budget_s=15.0):
                       f'{dt:.1f} s, torch {torch.__version__} with {best_t} threads (best of 8/16/32/64; host has {avail} hw threads)'}
 
 
-def pmc_traffic(args):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of THIS command
-    (profiles/pmc_r1.json, made by tools/profile.sh + tools/summarize_profile.py; FETCH_SIZE x2 on gfx950 as
-    MI355X_MICROARCH.md prescribes).  None when the configuration differs from the profiled one."""
-    path = os.path.join(ROOT, 'profiles', 'pmc_r1.json')
+# GEMM families of the encoder: profiling-family name -> (kernel symbol prefix in the rocprofv3 trace, description)
+FAMILIES = {
+    'gemm_fc1': ('gemm8_kernel<{T}, 1,', 'mlp.fc1 (+LayerNorm fold +bias +GELU), 8-phase persistent kernel, 256x256 tiles'),
+    'gemm_fc2': ('gemm8_kernel<{T}, 6,', 'mlp.fc2 (+bias +residual planes +LayerNorm row statistics), 8-phase kernel, 256x192 tiles'),
+    'gemm_qkv': ('gemm8_kernel<{T}, 0,', 'attn.qkv (+LayerNorm fold +bias), 8-phase persistent kernel, 256x256 tiles'),
+    'gemm_proj': ('gemm_kernel<{T}, 6, 0', 'attn.proj (+bias +residual planes +LayerNorm row statistics), 192x128 tiles'),
+}
+
+
+def pmc_traffic(args, fam):
+    """HBM bytes per launch of a kernel family from the committed rocprofv3 PMC passes of THIS command (profiles/pmc_r2.json,
+    made by tools/profile.sh + tools/summarize_profile.py; FETCH_SIZE x2 on gfx950 as MI355X_MICROARCH.md prescribes).
+    PMC passes cannot run inside this process, so the figure is read from the committed profile of the same configuration;
+    None when the configuration differs from the profiled one."""
+    path = os.path.join(ROOT, 'profiles', 'pmc_r2.json')
     if not (os.path.exists(path) and args.variant == 'b' and args.batch == 256 and args.dtype == 'fp16' and args.gpus == 1):
         return None
+    pre = FAMILIES[fam][0].format(T='F16' if args.dtype == 'fp16' else 'BF16')
     try:
         for k, d in json.load(open(path)).items():
-            if k.startswith('gemm_kernel<F16, 6, 0') and 'hbm_bytes_per_dispatch' in d:
+            if k.startswith(pre) and 'hbm_bytes_per_dispatch' in d:
                 return d['hbm_bytes_per_dispatch']
     except Exception:
         pass
     return None
 
 
+def host_path_rate(eng, crops_u8, K, seconds=1.5):
+    """persons/s of the host-visible path: uint8 crops in pinned host memory -> keypoints in pinned host memory, through
+    vp_infer_submit / vp_infer_wait (H2D of batch i+1 and D2H of batch i-1 under the compute of batch i)."""
+    from easy_vitpose_amd import PinnedArray
+    B = crops_u8.shape[0]
+    pin_in = [PinnedArray(crops_u8.shape, np.uint8) for _ in range(2)]
+    pin_out = [PinnedArray((B, K, 3), np.float32) for _ in range(2)]
+    for p in pin_in:
+        p.array[...] = crops_u8
+    pending = []
+    def push(i):
+        pending.append(eng.submit(pin_in[i & 1].array, pin_out[i & 1].array))
+    for i in range(3):          # warm
+        push(i)
+        if len(pending) == 2:
+            eng.wait(pending.pop(0))
+    while pending:
+        eng.wait(pending.pop(0))
+    n, t0 = 0, time.perf_counter()
+    while True:
+        push(n)
+        n += 1
+        if len(pending) == 2:
+            eng.wait(pending.pop(0))
+        if time.perf_counter() - t0 > seconds and n >= 20:
+            break
+    while pending:
+        eng.wait(pending.pop(0))
+    dt = time.perf_counter() - t0
+    assert np.isfinite(pin_out[0].array).all()
+    for p in pin_in + pin_out:
+        p.free()
+    return n * B / dt
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--steps', type=int, default=100)
+    ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--dtype', default='fp16', choices=['fp16', 'bf16'])
     ap.add_argument('--batch', type=int, default=256)
     ap.add_argument('--max-batch', type=int, default=0, help='workspace batch of the handle (< --batch: the batch is processed in chunks)')
@@ -101,6 +147,7 @@ def main():
     ap.add_argument('--dataset', default='coco')
     ap.add_argument('--input', default='f32', choices=['f32', 'u8'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-host-path', action='store_true')
     ap.add_argument('--breakdown', action='store_true', help='extra untimed pass with every kernel family timed (stderr)')
     ap.add_argument('--force-dist', action='store_true', help='run the RCCL code path (process group, all-gather, barrier) even with one rank')
     args = ap.parse_args()
@@ -149,13 +196,17 @@ def main():
         if use_dist:
             dist.barrier()
 
+    fams = list(FAMILIES)
+    eng.set_profiling(fams)      # warm-up pass with all four encoder GEMM families timed: picks the dominant one
+    eng.reset_profile()
     for _ in range(args.warmup):
         step()
-    # dominant kernel symbol by total time (rocprofv3 --stats, profiles/r1_tuned_path_rocprofv3.txt): the GEMM with
-    # the bias + residual + LayerNorm-statistics epilogue (gemm_kernel<F16, 6, 0, ...> = EPI_BIAS_RESID_LN), launched
-    # 24x per step (attn.proj K=D and mlp.fc2 K=4D, both N=D)
-    dom = 'gemm_proj_fc2'
-    eng.set_profiling([dom])
+    fence()
+    wprof = eng.profile()
+    dom = max(fams, key=lambda f: wprof[f]['ms']) if args.warmup > 0 else 'gemm_fc1'
+    # the four encoder GEMM families are timed live (HIP events around every launch, on the library's stream); the one with
+    # the largest share of the step is reported as the dominant kernel (rocprofv3 --stats of the same command: profiles/)
+    eng.set_profiling([dom])     # timed region: only the dominant family carries event records (2 per launch)
     eng.reset_profile()
     fence()
     t0 = time.perf_counter()
@@ -173,6 +224,18 @@ def main():
         assert torch.equal(d_all[rank * B:(rank + 1) * B], d_out), 'all-gather result differs from the local shard'
     assert torch.isfinite(d_out).all(), 'non-finite keypoints'
 
+    # per-step distribution (separate, untimed-for-`value` pass with a host synchronisation after every step)
+    step_ms = []
+    for _ in range(min(args.steps, 50)):
+        fence()
+        t1 = time.perf_counter()
+        step()
+        fence()
+        step_ms.append((time.perf_counter() - t1) * 1e3)
+    host_rate = None
+    if rank == 0 and world == 1 and not args.no_host_path:
+        host_rate = host_path_rate(eng, crops_u8, K)
+
     breakdown = None
     if args.breakdown and rank == 0:
         eng.set_profiling(True); eng.reset_profile()
@@ -188,6 +251,10 @@ def main():
         persons_s = world * B * args.steps / dt
         d = prof[dom]
         ach = d['flops'] / (d['ms'] * 1e-3) if d['ms'] > 0 else 0.0
+        T = 'F16' if args.dtype == 'fp16' else 'BF16'
+        per_family = {f: {'ms_per_step': round(wprof[f]['ms'] / max(args.warmup, 1), 4), 'avg_launch_us': round(1e3 * wprof[f]['ms'] / max(wprof[f]['launches'], 1), 2),
+                          'tflops': round(wprof[f]['flops'] / max(wprof[f]['ms'], 1e-9) / 1e9, 1),
+                          'algorithmic_gbps': round(wprof[f]['bytes'] / max(wprof[f]['ms'], 1e-9) / 1e6, 1)} for f in fams}   # from the warm-up pass
         line = {
             'metric': 'persons_per_sec', 'value': round(persons_s, 1), 'unit': 'persons/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -200,11 +267,16 @@ def main():
                        'gflop_per_person': round(shp.gflop_per_person(), 3)},
             'model_tflops': round(persons_s * shp.gflop_per_person() / 1e3, 1),
             'model_frac_of_mfma_peak': round(persons_s * shp.gflop_per_person() * 1e9 / PEAK_MFMA_16BIT, 4),
-            'roofline': {'bound': 'mfma', 'kernel': 'gemm_kernel<F16, EPI_BIAS_RESID_LN, A_DENSE, TileCfg<192,128,64,48,64,2,1,0>> (attn.proj + mlp.fc2: +bias +residual planes +LayerNorm row statistics; flops = average of the two shapes)',
+            'roofline': {'bound': 'mfma', 'kernel': FAMILIES[dom][0].format(T=T) + ' ...>: ' + FAMILIES[dom][1],
                          'achieved': round(ach / 1e12, 2), 'peak': PEAK_MFMA_16BIT / 1e12, 'unit': 'TFLOP/s',
-                         'frac': round(ach / PEAK_MFMA_16BIT, 4), 'traffic': pmc_traffic(args),
+                         'frac': round(ach / PEAK_MFMA_16BIT, 4), 'traffic': pmc_traffic(args, dom),
                          'launches': d['launches'], 'avg_launch_ms': round(d['ms'] / max(d['launches'], 1), 5),
-                         'flops_per_launch_avg': d['flops'] / max(d['launches'], 1)},
+                         'flops_per_launch': d['flops'] / max(d['launches'], 1),
+                         'algorithmic_bytes_per_launch': d['bytes'] / max(d['launches'], 1)},
+            'encoder_gemms': per_family,
+            'step_ms': {'p10': round(float(np.percentile(step_ms, 10)), 4), 'p50': round(float(np.percentile(step_ms, 50)), 4),
+                        'p90': round(float(np.percentile(step_ms, 90)), 4), 'n': len(step_ms), 'note': 'one host synchronisation per step'},
+            'host_persons_per_sec': None if host_rate is None else round(host_rate, 1),
         }
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(args.variant, args.dataset)

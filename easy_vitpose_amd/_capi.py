@@ -15,8 +15,8 @@ LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), '_lib', 'lib
 VP_OK, VP_ERR_INVALID, VP_ERR_HIP, VP_ERR_STATE, VP_ERR_MISSING_TENSOR, VP_ERR_SHAPE = range(6)
 VP_DTYPE_F16, VP_DTYPE_BF16 = 0, 1
 VP_INPUT_F32_NCHW, VP_INPUT_U8_NHWC = 0, 1
-VP_PROF_NAMES = ['gemm_proj_fc2', 'gemm_fc1', 'gemm_qkv', 'gemm_patch', 'gemm_deconv', 'gemm_final',
-                 'attention', 'layernorm', 'im2col', 'decode']
+VP_PROF_NAMES = ['gemm_proj', 'gemm_fc1', 'gemm_qkv', 'gemm_patch', 'gemm_deconv', 'gemm_final',
+                 'attention', 'layernorm', 'im2col', 'decode', 'gemm_fc2']
 VP_PROF_COUNT = len(VP_PROF_NAMES)
 DTYPES = {'fp16': VP_DTYPE_F16, 'f16': VP_DTYPE_F16, 'bf16': VP_DTYPE_BF16}
 

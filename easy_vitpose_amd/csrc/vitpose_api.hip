@@ -83,7 +83,7 @@ struct vp_ctx {
     int32_t* partner = nullptr;       // flip-test: mirror joint per joint
     bool g8_deferred = false;         // wide GEMMs on the deferred-quadrant-epilogue variant of gemm8 (VP_G8_DEFERRED=1; measured slower)
     int g8_stagger = 0;               // gemm8: start delay per XCD in sleep quanta (VP_G8_STAGGER)
-    int gemm8_mask = 0x7;             // kernel families on the 8-phase kernel at large batch: bit VP_PROF_GEMM_PROJ / _FC1 / _QKV (VP_GEMM8)
+    int gemm8_mask = 0x7;             // GEMMs on the 8-phase kernel at large batch: 1 fc2, 2 fc1, 4 qkv, 8 proj (VP_GEMM8; proj measured slower)
     bool persist_gemm = true;         // qkv / fc1 as persistent workgroups at large batch (VP_PERSIST=0: one tile per workgroup)
     int order_mask = 8;               // tile walk last-to-first per GEMM: bit0 qkv, bit1 proj, bit2 fc1, bit3 fc2 (VP_ORDER)
     bool blocked_hid = true;          // mlp hidden activations in the 64x64-blocked layout (VP_BLOCKED_HID=0: row-major)
@@ -107,7 +107,7 @@ struct vp_ctx {
     int32_t* cparams = nullptr;       // per-crop geometry [max_batch, 8]
     // profiling
     uint32_t prof = 0;   // bit f = time kernel family f
-    int gemm_variant[VP_PROF_COUNT] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1};   // tile cfg per GEMM family, -1 = default rule
+    int gemm_variant[VP_PROF_COUNT] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1};   // tile cfg per GEMM family, -1 = default rule
     int gemm_group_m[VP_PROF_COUNT] = {0};
     int gemm_ablate = 0;   // profiling only
     struct Ev { hipEvent_t a, b; int fam; double flops, bytes; };
@@ -376,7 +376,9 @@ int gemm(vp_ctx* c, int fam, int epi, const uint16_t* A, const uint16_t* W, cons
     // (attn.proj, K = N = D, is HBM-bound and stays on the 192 x 128 tile with two workgroups per CU: measured 105 vs 112 us;
     // bit 3 of VP_GEMM8 moves it too)
     const bool is_proj = epi == vp::EPI_BIAS_RESID_LN && K <= N;
-    if (c->gemm_variant[fam] < 0 && (c->gemm8_mask >> fam) & 1 && (!is_proj || (c->gemm8_mask & 8)) &&
+    const int g8bit = fam == VP_PROF_GEMM_FC2 ? 1 : fam == VP_PROF_GEMM_FC1 ? 2 : fam == VP_PROF_GEMM_QKV ? 4 : fam == VP_PROF_GEMM_PROJ ? 8 : 0;
+    (void)is_proj;
+    if (c->gemm_variant[fam] < 0 && (c->gemm8_mask & g8bit) &&
         (epi == vp::EPI_BIAS || epi == vp::EPI_BIAS_GELU || epi == vp::EPI_BIAS_RESID_LN) && M % 256 == 0) {
         const bool wide = epi != vp::EPI_BIAS_RESID_LN;
         int bn = 0;
@@ -438,7 +440,7 @@ int forward_chunk(vp_ctx* c, const void* d_crops, int fmt, int n, bool want_toke
             LnFuse c1; c1.rowstat = c->rowstat; c1.ln_s = b.s_fc1; c1.out_blocked = c->blocked_hid; c1.reverse = (c->order_mask & 4) != 0;
             if ((rc = gemm(c, VP_PROF_GEMM_FC1, vp::EPI_BIAS_GELU, xh, b.w_fc1, b.b_fc1, c->hid, nullptr, M, 4 * D, D, 4 * D, 0, 0, 0, &c1))) return rc;
             LnFuse p2 = prod; p2.a_blocked = c->blocked_hid; p2.reverse = (c->order_mask & 8) != 0;
-            if ((rc = gemm(c, VP_PROF_GEMM_PROJ, vp::EPI_BIAS_RESID_LN, c->hid, b.w_fc2, b.b_fc2, c->x, c->x, M, D, 4 * D, D, 0, 0, 0, &p2))) return rc;
+            if ((rc = gemm(c, VP_PROF_GEMM_FC2, vp::EPI_BIAS_RESID_LN, c->hid, b.w_fc2, b.b_fc2, c->x, c->x, M, D, 4 * D, D, 0, 0, 0, &p2))) return rc;
             if (l + 1 < c->L && (rc = finalize())) return rc;   // last block: last_norm below is a standalone pass
         }
     } else {
@@ -454,7 +456,7 @@ int forward_chunk(vp_ctx* c, const void* d_crops, int fmt, int n, bool want_toke
         LAUNCH(c, VP_PROF_LAYERNORM, 0.0, 6.0 * M * D,
                vp::layernorm_launch(c->dtype, c->x, b.ln2_g, b.ln2_b, c->y, nullptr, M, D, c->stream));
         if ((rc = gemm(c, VP_PROF_GEMM_FC1, vp::EPI_BIAS_GELU, c->y, b.w_fc1, b.b_fc1, c->hid, nullptr, M, 4 * D, D, 4 * D))) return rc;
-        if ((rc = gemm(c, VP_PROF_GEMM_PROJ, vp::EPI_BIAS_RESID, c->hid, b.w_fc2, b.b_fc2, c->x, c->x, M, D, 4 * D, D))) return rc;
+        if ((rc = gemm(c, VP_PROF_GEMM_FC2, vp::EPI_BIAS_RESID, c->hid, b.w_fc2, b.b_fc2, c->x, c->x, M, D, 4 * D, D))) return rc;
     }
     }
     LAUNCH(c, VP_PROF_LAYERNORM, 0.0, 6.0 * M * D,

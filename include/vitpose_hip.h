@@ -79,7 +79,7 @@ typedef struct vp_tensor_desc {
 } vp_tensor_desc;
 
 /* Per-kernel-family timing collected with HIP events on the handle's stream. */
-#define VP_PROF_GEMM_PROJ 0  /* proj/fc2 GEMM  (bias + residual + LayerNorm statistics)  -- dominant kernel */
+#define VP_PROF_GEMM_PROJ 0  /* attn.proj GEMM (bias + residual planes + LayerNorm statistics), HBM-bound */
 #define VP_PROF_GEMM_FC1 1   /* fc1 GEMM (bias + GELU)                     */
 #define VP_PROF_GEMM_QKV 2   /* qkv GEMM (bias)                            */
 #define VP_PROF_GEMM_PATCH 3 /* patch-embed GEMM (bias + pos)              */
@@ -89,7 +89,8 @@ typedef struct vp_tensor_desc {
 #define VP_PROF_LAYERNORM 7
 #define VP_PROF_IM2COL 8
 #define VP_PROF_DECODE 9
-#define VP_PROF_COUNT 10
+#define VP_PROF_GEMM_FC2 10  /* mlp.fc2 GEMM (same epilogue as proj, K = 4 D) */
+#define VP_PROF_COUNT 11
 
 typedef struct vp_profile {
     double ms[VP_PROF_COUNT];      /* summed kernel time since the last reset  */
