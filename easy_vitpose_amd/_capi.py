@@ -26,7 +26,7 @@ SYMBOLS = ['vp_abi_version', 'vp_create', 'vp_load_weights', 'vp_infer', 'vp_inf
            'vp_group_infer_allgather', 'vp_group_destroy', 'vp_group_last_error', 'vp_infer_frame', 'vp_infer_flip', 'vp_infer_heatmaps',
            'vp_infer_tokens', 'vp_decode_only', 'vp_stream', 'vp_synchronize', 'vp_set_profiling',
            'vp_reset_profile', 'vp_get_profile', 'vp_destroy', 'vp_last_error',
-           'vp_dbg_gemm', 'vp_dbg_attention', 'vp_dbg_layernorm', 'vp_dbg_deconv', 'vp_dbg_gemm_bench', 'vp_dbg_gemm_bench2', 'vp_dbg_gemm_compare', 'vp_dbg_gemm8_timeline', 'vp_dbg_gemm_timeline', 'vp_dbg_peak', 'vp_dbg_crop_prep']
+           'vp_dbg_gemm', 'vp_dbg_attention', 'vp_dbg_layernorm', 'vp_dbg_deconv', 'vp_dbg_gemm_bench', 'vp_dbg_gemm_case', 'vp_dbg_gemm_bench2', 'vp_dbg_gemm_compare', 'vp_dbg_gemm8_timeline', 'vp_dbg_gemm_timeline', 'vp_dbg_peak', 'vp_dbg_crop_prep']
 
 
 class HipExtensionMissing(RuntimeError):
@@ -116,6 +116,7 @@ def load_library():
     lib.vp_infer_flip.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
                                   C.c_void_p, C.c_void_p]
     lib.vp_dbg_gemm_bench.argtypes = [C.c_int32] * 9 + [C.POINTER(C.c_float)]
+    lib.vp_dbg_gemm_case.argtypes = [C.c_int32] * 9 + [C.c_void_p] * 8
     lib.vp_dbg_gemm_bench2.argtypes = [C.c_int32] * 10 + [C.POINTER(C.c_float)]
     lib.vp_dbg_gemm_compare.argtypes = [C.c_int32] * 13 + [C.POINTER(C.c_uint64), C.POINTER(C.c_double)]
     lib.vp_dbg_gemm8_timeline.argtypes = [C.c_int32] * 9 + [C.POINTER(C.c_uint64), C.c_int32]

@@ -1332,6 +1332,107 @@ int make_rand_case(vp_ctx* c, RandCase& rc, int epi, int flags, int M, int N, in
 }  // namespace
 extern "C" {
 
+// ONE launch of any production GEMM configuration on HOST fp32 data (tests/test_gpu_gemm_cfgs.py): operands are rounded to
+// `dtype` exactly as the packer / producing kernels round them, layouts (64x64-blocked A / output, two-plane residual stream,
+// hi+lo final-conv weights) are built and undone here.
+//   epi 0 / 1: out[M,N] 16-bit (returned as fp32); rowstat [M,2] + ln_s [N] non-NULL = LayerNorm-consumer fold
+//   epi 2 / 3: out[M,N] fp32, aux = residual [M,N] / pos [192,N]
+//   epi 6 / 7: aux = fp32 residual [M,N] (split into hi + lo planes on upload) / pos [192,N]; out = hi + lo planes summed;
+//              stats [M, N/64, 2] = (sum, centred M2) per 64-column granule
+//   epi 5:     W = final 1x1 conv weight [N = Kp, K = 256], A = [M = B 3072, 256]; out = heatmaps [B, Kp, 3072] fp32
+// flags: 1 persistent, 2 out_blocked, 4 a_blocked, 8 reverse
+VP_API int vp_dbg_gemm_case(int32_t device, int32_t dtype, int32_t epi, int32_t variant, int32_t group_m, int32_t flags, int32_t M,
+                            int32_t N, int32_t K, const float* A, const float* W, const float* bias, const float* aux, const float* rowstat,
+                            const float* ln_s, float* out, float* stats) {
+    if (M <= 0 || N <= 0 || K <= 0 || K % 64 || !A || !W || !bias || !out) return fail(nullptr, VP_ERR_INVALID, "bad gemm case");
+    vp_ctx* c = dbg_ctx(device, dtype);
+    if (!c) return VP_ERR_HIP;
+    c->Kp = N;
+    int r;
+    const size_t MN = (size_t)M * N, wrows = pad128(N);
+    const bool ablk = (flags & 4) != 0, oblk = (flags & 2) != 0;
+    uint16_t *dA, *dW;
+    float *dB, *dAux32 = nullptr, *dRow = nullptr, *dS = nullptr, *dStats = nullptr;
+    uint16_t* dAux16 = nullptr;
+    void* dOut = nullptr;
+    // A (optionally in the 64x64-blocked layout [M/64][K/64][64][64])
+    {
+        std::vector<uint16_t> ha((size_t)M * K);
+        for (size_t m = 0; m < (size_t)M; ++m)
+            for (size_t k = 0; k < (size_t)K; ++k) {
+                const size_t dst = ablk ? ((((m >> 6) * (K >> 6) + (k >> 6)) << 12) + ((m & 63) << 6) + (k & 63)) : m * K + k;
+                ha[dst] = host_to_bits(A[m * K + k], c->dtype);
+            }
+        if ((r = dalloc(c, &dA, (size_t)M * K))) return dbg_finish(c, r);
+        if (hipMemcpy(dA, ha.data(), ha.size() * 2, hipMemcpyHostToDevice) != hipSuccess) return dbg_finish(c, fail(c, VP_ERR_HIP, "H2D"));
+    }
+    size_t fin_rows = 0;
+    if (epi == vp::EPI_HEATMAP) { if ((r = upload_final(c, &dW, W, N, K, &fin_rows))) return dbg_finish(c, r); }
+    else if ((r = upload_mat(c, &dW, W, N, K, wrows))) return dbg_finish(c, r);
+    if ((r = upload_f32(c, &dB, bias, N, wrows)) || (r = dalloc(c, &c->zero, (size_t)256))) return dbg_finish(c, r);
+    vp::GemmArgs g{};
+    g.A = dA; g.W = dW; g.bias = dB; g.M = M; g.N = N; g.K = K; g.ldo = N; g.zero = c->zero; g.Kp = N;
+    g.w_rows = (int)wrows; g.variant = variant; g.group_m = group_m;
+    g.persist = (flags & 1) != 0; g.out_blocked = oblk; g.a_blocked = ablk; g.reverse = (flags & 8) != 0;
+    if (rowstat && ln_s) {
+        if ((r = upload_f32(c, &dRow, rowstat, (size_t)M * 2)) || (r = upload_f32(c, &dS, ln_s, N, wrows))) return dbg_finish(c, r);
+        g.rowstat = dRow; g.ln_s = dS;
+    }
+    size_t out_bytes = 0;
+    const bool prod = epi == vp::EPI_BIAS_RESID_LN || epi == vp::EPI_POS_LN;
+    if (epi == vp::EPI_BIAS || epi == vp::EPI_BIAS_GELU) out_bytes = MN * 2;
+    else if (epi == vp::EPI_BIAS_RESID || epi == vp::EPI_POS || prod) out_bytes = MN * 4;
+    else if (epi == vp::EPI_HEATMAP) { out_bytes = MN * 4; g.N = (int)fin_rows; g.ldo = 0; g.w_rows = (int)pad128(fin_rows); }
+    else return dbg_finish(c, fail(c, VP_ERR_INVALID, "unsupported epilogue"));
+    if (epi == vp::EPI_BIAS_RESID || epi == vp::EPI_POS || epi == vp::EPI_POS_LN) {
+        if (!aux) return dbg_finish(c, fail(c, VP_ERR_INVALID, "aux required"));
+        if ((r = upload_f32(c, &dAux32, aux, epi == vp::EPI_BIAS_RESID ? MN : (size_t)192 * N))) return dbg_finish(c, r);
+        g.aux = dAux32;
+    }
+    if (epi == vp::EPI_BIAS_RESID_LN) {
+        if (!aux) return dbg_finish(c, fail(c, VP_ERR_INVALID, "aux required"));
+        std::vector<uint16_t> hp(2 * MN);
+        for (size_t i = 0; i < MN; ++i) {
+            const uint16_t hi = host_to_bits(aux[i], c->dtype);
+            hp[i] = hi;
+            hp[MN + i] = host_to_bits(aux[i] - host_from_bits(hi, c->dtype), c->dtype);
+        }
+        if ((r = dalloc(c, &dAux16, 2 * MN))) return dbg_finish(c, r);
+        if (hipMemcpy(dAux16, hp.data(), hp.size() * 2, hipMemcpyHostToDevice) != hipSuccess) return dbg_finish(c, fail(c, VP_ERR_HIP, "H2D"));
+        g.aux = (const float*)dAux16;
+    }
+    if (prod) {
+        g.plane = MN;
+        if ((r = dalloc(c, &dStats, (size_t)M * (N / 64) * 2))) return dbg_finish(c, r);
+        g.stats_out = dStats;
+    }
+    char* o;
+    if ((r = dalloc(c, &o, out_bytes))) return dbg_finish(c, r);
+    dOut = o;
+    hipMemset(dOut, 0xff, out_bytes);
+    g.out = dOut;
+    hipError_t e = vp::gemm_launch(c->dtype, epi, g, nullptr);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e != hipSuccess) return dbg_finish(c, fail(c, VP_ERR_HIP, std::string("gemm case: ") + hipGetErrorString(e)));
+    if (epi == vp::EPI_BIAS || epi == vp::EPI_BIAS_GELU) {
+        std::vector<float> t(MN);
+        if ((r = download16(c, (const uint16_t*)dOut, t.data(), MN))) return dbg_finish(c, r);
+        for (size_t m = 0; m < (size_t)M; ++m)
+            for (size_t n = 0; n < (size_t)N; ++n) {
+                const size_t src = oblk ? ((((m >> 6) * ((size_t)N >> 6) + (n >> 6)) << 12) + ((m & 63) << 6) + (n & 63)) : m * N + n;
+                out[m * N + n] = t[src];
+            }
+    } else if (prod) {
+        std::vector<float> hi(MN), lo(MN);
+        if ((r = download16(c, (const uint16_t*)dOut, hi.data(), MN)) || (r = download16(c, (const uint16_t*)dOut + MN, lo.data(), MN))) return dbg_finish(c, r);
+        for (size_t i = 0; i < MN; ++i) out[i] = hi[i] + lo[i];
+        if (stats && hipMemcpy(stats, dStats, (size_t)M * (N / 64) * 8, hipMemcpyDeviceToHost) != hipSuccess) return dbg_finish(c, fail(c, VP_ERR_HIP, "D2H"));
+    } else {
+        if (hipMemcpy(out, dOut, out_bytes, hipMemcpyDeviceToHost) != hipSuccess) return dbg_finish(c, fail(c, VP_ERR_HIP, "D2H"));
+    }
+    return dbg_finish(c, VP_OK);
+}
+
 // average milliseconds per launch of one production GEMM configuration on random operands
 VP_API int vp_dbg_gemm_bench2(int32_t device, int32_t dtype, int32_t epi, int32_t variant, int32_t group_m, int32_t flags, int32_t M,
                               int32_t N, int32_t K, int32_t iters, float* ms_out) {

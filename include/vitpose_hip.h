@@ -239,6 +239,11 @@ VP_API int vp_dbg_gemm_bench(int32_t device_id, int32_t dtype, int32_t epi, int3
  * flags: 1 persistent workgroups, 2 64x64-blocked output, 4 64x64-blocked A operand, 8 reversed tile walk, 16 LayerNorm-consumer fold.
  * bench2: average milliseconds per launch.  compare: both configurations on the same operands, `reps` times; counts every
  * differing output element / statistic (two kernels with the same accumulation order must agree bit for bit). */
+/* one launch of a production configuration on HOST data (layouts built / undone inside): epi 0-3, 5 (final 1x1 conv with hi+lo
+ * weights -> heatmaps [M/3072, N, 3072]), 6, 7; rowstat [M,2] + ln_s [N] = LayerNorm-consumer fold; stats [M, N/64, 2] (epi 6 / 7) */
+VP_API int vp_dbg_gemm_case(int32_t device_id, int32_t dtype, int32_t epi, int32_t variant, int32_t group_m, int32_t flags,
+                            int32_t M, int32_t N, int32_t K, const float* A, const float* W, const float* bias, const float* aux,
+                            const float* rowstat, const float* ln_s, float* out, float* stats);
 VP_API int vp_dbg_gemm_bench2(int32_t device_id, int32_t dtype, int32_t epi, int32_t variant, int32_t group_m, int32_t flags,
                               int32_t M, int32_t N, int32_t K, int32_t iters, float* ms_out);
 VP_API int vp_dbg_gemm_compare(int32_t device_id, int32_t dtype, int32_t epi, int32_t variant_a, int32_t group_a, int32_t flags_a,

@@ -222,6 +222,11 @@ def test_baseline_batch_properties():
     assert out.shape == (256, 17, 3) and np.isfinite(out).all()
     idx = [0, 3, 100, 255]
     assert np.array_equal(np.concatenate([eng.infer(crops[i:i + 1]) for i in idx]), out[idx])
+    # ALL 256 crops against the small-batch path (64x64 / 128x128 tiles, one tile per workgroup, no 8-phase kernel): the
+    # production kernels of the BASELINE batch must reproduce it bit for bit
+    small = VitPoseHip(shp, sd, dtype='fp16', max_batch=8)
+    assert np.array_equal(small.infer(crops), out)
+    small.close()
     ref_hm = oracle_heatmaps('b', 'coco', crops[idx])
     ref = O.decode_per_crop(ref_hm)
     assert np.abs(out[idx][..., 2] - ref[..., 2]).max() < CONF_TOL
