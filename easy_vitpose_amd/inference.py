@@ -144,10 +144,11 @@ class VitInference:
         use_tracker = self.is_video and not self.single_pose
         self.tracker = None
         if use_tracker:
-            if self._tracker_factory is None:
-                raise NotImplementedError('is_video tracking needs a SORT-like tracker: pass tracker=<factory> '
-                                          '(the CPU tracker is outside the HIP hot path)')
-            self.tracker = self._tracker_factory()
+            if self._tracker_factory is None:   # the reference's own choice and parameters (inference.py:182-184)
+                from .tracker import Sort
+                self.tracker = Sort(max_age=self.yolo_step, min_hits=3, iou_threshold=0.3)
+            else:
+                self.tracker = self._tracker_factory()
         self.frame_counter = 0
 
     @classmethod

@@ -94,3 +94,25 @@ def peaked_crops(n: int):
     """Half blob crops, half uniform-noise crops (seeds 21 / 22)."""
     from easy_vitpose_amd.synth import synthetic_crops
     return np.concatenate([synthetic_crops(n // 2, 21, 'blobs'), synthetic_crops(n - n // 2, 22, 'noise')])
+
+
+def tracker_sequence():
+    """Detections [n, 5] (x1, y1, x2, y2, score) per frame for the tracker golden: three people walking (one of them missed by
+    the detector on two frames), a fourth entering at frame 6, two crossing paths, and detector-skipped (empty) frames as
+    `yolo_step > 1` produces them."""
+    rng = np.random.default_rng(77)
+    frames = []
+    for f in range(24):
+        dets = []
+        people = [(100 + 6 * f, 200 + 1 * f, 80, 200, 0.90), (500 - 5 * f, 180, 90, 220, 0.80), (300 + 2 * f, 100 + 4 * f, 60, 150, 0.70)]
+        if f >= 6:
+            people.append((50 + 9 * (f - 6), 300, 70, 180, 0.60))
+        for i, (x, y, w, h, s) in enumerate(people):
+            if i == 1 and f in (9, 10):
+                continue                                   # missed detections
+            j = rng.normal(0, 1.5, size=4)
+            dets.append([x + j[0], y + j[1], x + w + j[2], y + h + j[3], s + 0.001 * f])
+        if f in (4, 13, 14, 19):
+            dets = []                                      # the detector did not run
+        frames.append(np.asarray(dets, dtype=np.float64).reshape(-1, 5))
+    return frames

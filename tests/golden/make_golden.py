@@ -93,6 +93,29 @@ def _install_stubs():
     cv2.resize = resize
     cv2.INTER_LINEAR = 1
 
+    # filterpy (absent) -- the reference's tracker (sort.py:30,104-119) only uses KalmanFilter(dim_x, dim_z) with the attributes
+    # x, P, Q, R, F, H and predict() / update(z): the textbook linear Kalman filter, restated here from filterpy's documented
+    # equations (P update in Joseph form).  PARITY UNPINNED vs the filterpy package itself.
+    class KalmanFilter:
+        def __init__(self, dim_x, dim_z):
+            self.x = np.zeros((dim_x, 1)); self.P = np.eye(dim_x); self.Q = np.eye(dim_x)
+            self.R = np.eye(dim_z); self.F = np.eye(dim_x); self.H = np.zeros((dim_z, dim_x))
+            self._I = np.eye(dim_x)
+
+        def predict(self):
+            self.x = self.F @ self.x
+            self.P = self.F @ self.P @ self.F.T + self.Q
+
+        def update(self, z):
+            z = np.asarray(z, dtype=np.float64).reshape(-1, 1)
+            y = z - self.H @ self.x
+            S = self.H @ self.P @ self.H.T + self.R
+            K = self.P @ self.H.T @ np.linalg.inv(S)
+            self.x = self.x + K @ y
+            IKH = self._I - K @ self.H
+            self.P = IKH @ self.P @ IKH.T + K @ self.R @ K.T
+    sys.modules['filterpy.kalman'].KalmanFilter = KalmanFilter
+
 
 def import_reference():
     _install_stubs()
@@ -221,6 +244,19 @@ def main():
         np.savez_compressed(os.path.join(HERE, f'model_{variant}_{dataset}.npz'), variant=variant, dataset=dataset,
                             n=n, kind=kind, crop_seed=7, weight_seed=0, heatmaps=hm_store.astype(np.float32),
                             keypoints=kps, stats=stats)
+
+    # ------------------------------------------------------- tracker golden (f-4)
+    # the reference's Sort (sort.py:203-266, constructed as inference.py:182-184 does) on a seeded detection sequence: moving
+    # boxes, a missed detection, a late entry, a crossing pair, detector-skipped frames (empty input -> predicted boxes)
+    from easy_ViTPose.sort import Sort as RefSort, KalmanBoxTracker
+    from cases import tracker_sequence
+    for tag, max_age in (('sort_age1', 1), ('sort_age3', 3)):
+        KalmanBoxTracker.count = 0
+        trk = RefSort(max_age=max_age, min_hits=3, iou_threshold=0.3)
+        outs = [np.asarray(trk.update(d.copy()), dtype=np.float64).reshape(-1, 6) for d in tracker_sequence()]
+        flat = np.concatenate([np.concatenate([np.full((len(o), 1), i, dtype=np.float64), o], 1) for i, o in enumerate(outs)])
+        print(f'tracker golden {tag}: {len(outs)} frames, {len(flat)} reported boxes, ids {sorted(set(flat[:, 6].astype(int)))}')
+        np.savez_compressed(os.path.join(HERE, f'{tag}.npz'), rows=flat, max_age=max_age)
 
     # ------------------------------------------------------- peaked-checkpoint goldens
     # synthetic_state_dict(peaked=True): one Gaussian-like blob per joint, so the reference's own keypoints are

@@ -132,3 +132,38 @@ def test_sharded_pose_over_rccl_with_the_real_engine():
     finally:
         dist.destroy_process_group()
         eng.close()
+
+
+def test_video_mode_with_tracker_and_cli(tmp_path):
+    """is_video=True: the built-in SORT tracker keeps ids across frames and predicts boxes on detector-skipped frames
+    (yolo_step = 2), and the CLI writes the reference's --save-json wire format for a .npy frame stack."""
+    import json
+    from easy_vitpose_amd import VitInference, cli
+    shp, sd, _ = weights('s', 'coco')
+    rng = np.random.default_rng(3)
+    frames = rng.integers(0, 256, size=(6, 360, 480, 3), dtype=np.uint8)
+    boxes = [[[40 + 5 * f, 60, 160 + 5 * f, 300, 0.9], [300 - 4 * f, 80, 400 - 4 * f, 320, 0.8]] for f in range(6)]
+    calls = {'n': 0}
+
+    def det(img):
+        calls['n'] += 1
+        return np.asarray(boxes[min(calls['n'] - 1, 5)], dtype=np.float64)
+
+    model = VitInference(sd, det, model_name='s', dataset='coco', is_video=True, yolo_step=2, max_batch=4)
+    seen = []
+    for f in range(6):
+        res = model.inference(frames[f])
+        seen.append(sorted(res.keys()))
+        assert all(v.shape == (17, 3) for v in res.values())
+    assert seen[0] == [1, 2] and all(s == [1, 2] for s in seen)          # stable ids, also on the frames where the detector is skipped
+    assert calls['n'] < 6                                                # ... which it was (frame_counter % yolo_step)
+    model.reset()
+    assert model.frame_counter == 0 and model.tracker is not None
+    np.save(tmp_path / 'clip.npy', frames)
+    (tmp_path / 'boxes.json').write_text(json.dumps(boxes))
+    rc = cli.main(['--input', str(tmp_path / 'clip.npy'), '--synthetic', 's', '--dataset', 'coco', '--boxes', str(tmp_path / 'boxes.json'),
+                   '--output-path', str(tmp_path / 'out'), '--save-json', '--max-batch', '4'])
+    assert rc == 0
+    out = json.load(open(tmp_path / 'out' / 'clip.npy' / 'clip_result.json'))
+    assert len(out['keypoints']) == 6 and out['skeleton']['0'] == 'nose'
+    assert sorted(out['keypoints'][0].keys()) == ['1', '2'] and len(out['keypoints'][0]['1']) == 17

@@ -227,3 +227,49 @@ def test_json_wire_format_like_reference_cli(tmp_path):
     assert d['skeleton']['0'] == 'nose' and len(d['skeleton']) == 17
     save_json(str(tmp_path / 'o.json'), frames)
     assert json.load(open(tmp_path / 'o.json'))['skeleton'] == {}
+
+
+# ----------------------------------------------------------------------------- tracker (f-4)
+@pytest.mark.parametrize('tag', ['sort_age1', 'sort_age3'])
+def test_tracker_matches_reference_sort(golden_dir, tag):
+    """easy_vitpose_amd.tracker.Sort against the output of the REFERENCE's Sort (sort.py:203-266, run by make_golden.py with a
+    textbook KalmanFilter in place of the absent filterpy) on a seeded detection sequence: same boxes, scores and ids per frame."""
+    import os
+    from cases import tracker_sequence
+    from easy_vitpose_amd.tracker import Sort
+    z = np.load(os.path.join(golden_dir, f'{tag}.npz'))
+    trk = Sort(max_age=int(z['max_age']), min_hits=3, iou_threshold=0.3)
+    rows = []
+    for i, d in enumerate(tracker_sequence()):
+        o = trk.update(d.copy()).reshape(-1, 6)
+        rows.append(np.concatenate([np.full((len(o), 1), i, dtype=np.float64), o], 1))
+    got = np.concatenate(rows)
+    assert got.shape == z['rows'].shape
+    assert np.array_equal(got[:, [0, 6]], z['rows'][:, [0, 6]])          # frame index and track id of every reported box
+    assert np.abs(got - z['rows']).max() < 1e-9
+
+
+def test_tracker_contract():
+    from easy_vitpose_amd.tracker import Sort, iou_matrix
+    assert Sort().update(np.empty((0, 5))).shape == (0, 6)
+    t = Sort(max_age=2, min_hits=3, iou_threshold=0.3)
+    box = np.array([[10., 10., 50., 90., 0.9]])
+    a = t.update(box)
+    assert a.shape == (1, 6) and a[0, 5] == 1                            # ids start at 1, young videos report at once
+    b = t.update(np.empty((0, 5)))                                       # detector skipped: the predicted box comes back
+    assert b.shape == (1, 6) and b[0, 5] == 1
+    assert abs(iou_matrix(box, box)[0, 0] - 1.0) < 1e-12
+    far = np.array([[400., 400., 450., 500., 0.8]])
+    c = t.update(np.concatenate([box, far]))
+    assert sorted(c[:, 5].astype(int).tolist()) == [1, 2]
+
+
+def test_cli_argument_surface():
+    """the CLI keeps the reference's option names (inference.py:148-187) and refuses what is outside the hot path loudly"""
+    from easy_vitpose_amd import cli
+    with pytest.raises(AssertionError):
+        cli.main(['--input', 'x.png', '--synthetic', 's', '--boxes', 'b.json', '--show'])
+    with pytest.raises(AssertionError):
+        cli.main(['--input', 'x.png', '--synthetic', 's', '--boxes', 'b.json', '--save-json'])     # needs --output-path
+    with pytest.raises(AssertionError):
+        cli.main(['--input', 'x.png', '--boxes', 'b.json'])                                        # no model
