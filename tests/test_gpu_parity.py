@@ -327,6 +327,12 @@ def test_device_crop_prep_bit_exact_and_frame_entry():
     host = prepare_crops_host(frame, p)
     dev = crop_prep_device(frame, p)
     assert np.array_equal(dev, host), f'{(dev != host).sum()} differing bytes'
+    # and against the INDEPENDENT checker (oracle/resize_ref.c: scalar-C restatement of OpenCV's resize, not the product's numpy)
+    from oracle.resize_ref import resize_linear_u8 as resize_ref
+    for i, (x0, y0, cw, ch, left, top, pw, ph) in enumerate(p):
+        canvas = np.zeros((ph, pw, 3), dtype=np.uint8)
+        canvas[top:top + ch, left:left + cw] = frame[y0:y0 + ch, x0:x0 + cw]
+        assert np.array_equal(dev[i], resize_ref(canvas, (192, 256))), f'crop {i} differs from the C oracle'
     shp, sd, _ = weights('s', 'coco')
     eng = VitPoseHip(shp, sd, dtype='fp16', max_batch=4)   # 7 crops -> chunks of 4 + 3
     a = eng.infer_frame(frame, p)

@@ -273,3 +273,20 @@ def test_cli_argument_surface():
         cli.main(['--input', 'x.png', '--synthetic', 's', '--boxes', 'b.json', '--save-json'])     # needs --output-path
     with pytest.raises(AssertionError):
         cli.main(['--input', 'x.png', '--boxes', 'b.json'])                                        # no model
+
+
+# ----------------------------------------------------------------------------- resize (f-1)
+def test_host_resize_matches_independent_c_oracle():
+    """cropprep.resize_linear_u8 (numpy, product host code) against oracle/resize_ref.c, an independent scalar-C restatement of
+    OpenCV's 8-bit INTER_LINEAR written from the published algorithm: down- and up-scaling, the exact-2x box path, degenerate
+    sizes.  Breaks the circle `device == product host code == golden generator's cv2 stub`."""
+    from easy_vitpose_amd.cropprep import resize_linear_u8
+    from oracle.resize_ref import resize_linear_u8 as ref
+    rng = np.random.default_rng(5)
+    for h, w in [(256, 192), (512, 384), (300, 100), (100, 300), (257, 193), (1, 1), (64, 47), (63, 48), (480, 640), (333, 250),
+                 (10, 7), (128, 96), (1024, 768), (37, 1000), (2, 3), (255, 191)]:
+        img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        assert np.array_equal(resize_linear_u8(img, (192, 256)), ref(img, (192, 256))), (h, w)
+    img = rng.integers(0, 256, (90, 70, 3), dtype=np.uint8)
+    for dw, dh in [(35, 45), (140, 180), (71, 89), (1, 1)]:
+        assert np.array_equal(resize_linear_u8(img, (dw, dh)), ref(img, (dw, dh))), (dw, dh)
