@@ -386,7 +386,7 @@ int gemm(vp_ctx* c, int fam, int epi, const uint16_t* A, const uint16_t* W, cons
         else bn = (N % 192 == 0 && (long)(M / 256) * (N / 192) % 256 == 0) ? 192 : (N % 256 == 0 ? 256 : (N % 192 == 0 ? 192 : 0));
         if (bn && (long)(M / 256) * (N / bn) >= 512 && vp::gemm8_supported(epi, g, bn)) {
             g.variant = bn == 256 ? (wide && c->g8_deferred ? 19 : 16) : 17;
-            g.group_m = 8;
+            g.group_m = fam == VP_PROF_GEMM_QKV ? 4 : fam == VP_PROF_GEMM_FC2 ? 2 : 8;   // measured sweep 0 / 2 / 4 / 8 / 16 / 32 (spread 2-3 %)
             g.persist = 0;
             g.stagger = c->g8_stagger;
         }
