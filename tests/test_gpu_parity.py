@@ -129,14 +129,30 @@ def test_model_parity_vs_oracle(variant, dataset, n, dtype):
     cerr = np.abs(kp[..., 2] - ref_kp[..., 2])
     print(f'[{variant}/{dtype}] confidence max err {cerr.max():.3e} (tol {CONF_ERR[dtype]:.1e})')
     assert cerr.max() < CONF_ERR[dtype]
-    # coordinates: joints whose arg-max cannot flip under the measured error and whose DARK step is
-    # well-posed in the reference itself (helpers.dark_conditioned); noise-like maps mostly are not
+    # coordinates on these noise-like maps: only where the arg-max cannot flip under the measured error and the DARK step is
+    # well-posed in the reference itself (a handful of joints); the real coordinate assertion -- EVERY joint -- is the peaked
+    # checkpoint below and test_peaked_checkpoint_end_to_end_vs_reference_golden
     ok = (argmax_margin(ref_hm) > 4 * err.max()) & dark_conditioned(ref_hm) & (dark_offset_px(ref_kp, ref_hm) < 1.5)
-    print(f'[{variant}/{dtype}] coordinate check on {ok.sum()} of {ok.size} joints')
-    assert ok.sum() >= (6 if dtype == 'fp16' else 1)
-    d = np.abs(kp[..., :2] - ref_kp[..., :2])[ok]
-    print(f'[{variant}/{dtype}] keypoint max err {d.max():.3f} px')
-    assert d.max() < KP_TOL_PX
+    if ok.any():
+        d = np.abs(kp[..., :2] - ref_kp[..., :2])[ok]
+        print(f'[{variant}/{dtype}] noise maps: keypoint max err {d.max():.3f} px on the {ok.sum()} conditioned joints of {ok.size}')
+        assert d.max() < KP_TOL_PX
+    # the same crops through the PEAKED checkpoint of this variant, against the oracle computed here: all joints
+    from easy_vitpose_amd.synth import synthetic_state_dict
+    from easy_vitpose_amd.configs import model_shape
+    shp = model_shape(variant, dataset)
+    psd = synthetic_state_dict(shp, 0, peaked=True)
+    peng = VitPoseHip(shp, psd, dtype=dtype, device_id=0, max_batch=16)
+    pkp = peng.infer(crops)
+    peng.close()
+    psdt = O.to_torch_state_dict(psd)
+    pref = np.concatenate([O.inference_torch(psdt, shp.depth, shp.num_heads, c) for c in crops])
+    dpx, dcf = np.abs(pkp[..., :2] - pref[..., :2]).max(-1), np.abs(pkp[..., 2] - pref[..., 2])
+    print(f'[{variant}/{dtype}] peaked checkpoint, {dpx.size} joints: coordinate max err {dpx.max():.4f} px, confidence max err {dcf.max():.3e}')
+    if dtype == 'fp16':
+        assert dpx.max() < KP_TOL_PX and dcf.max() < CONF_TOL
+    else:   # bf16 operands: coordinates hold, confidences do not meet 1e-3
+        assert dpx.max() < KP_TOL_PX and dcf.max() < CONF_ERR['bf16']
     # composition check on REALISTIC maps: add the measured device error tensor to peaked (trained-model-like)
     # heatmaps and decode both -- every joint must stay within the north_star tolerances
     pk = peaked_heatmaps(n, ref_hm.shape[1], 31)[:, :, :, :]
