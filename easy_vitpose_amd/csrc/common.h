@@ -96,6 +96,21 @@ __device__ __forceinline__ float ln_fold(float acc, float mean, float s, float r
     return __builtin_fmaf(__builtin_fmaf(-mean, s, acc), rstd, b);
 }
 
+// Fused-LayerNorm statistics: fold the per-granule (sum, M2 about the granule mean) partials of one row, in granule order, into
+// (mean, rstd) with the pairwise-merge identity  M2 = sum_g [M2_g + 64 (mean_g - mean)^2].  ONE definition for ln_finalize_kernel
+// and for the GEMM epilogues that fold it in at small batch: identical operation sequence, hence identical bits.
+__device__ __forceinline__ void ln_merge(const float* __restrict__ p, int tiles, float inv_d, float& mean, float& rstd) {
+    float s1 = 0.f;
+    for (int t = 0; t < tiles; ++t) s1 += p[2 * t];
+    mean = s1 * inv_d;
+    float m2 = 0.f;
+    for (int t = 0; t < tiles; ++t) {
+        const float d = __builtin_fmaf(p[2 * t], 1.0f / 64.0f, -mean);
+        m2 += __builtin_fmaf(64.0f * d, d, p[2 * t + 1]);
+    }
+    rstd = rsqrtf(__builtin_fmaf(m2, inv_d, 1e-6f));
+}
+
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef __attribute__((address_space(1))) const void* gbl_ptr_t;
 

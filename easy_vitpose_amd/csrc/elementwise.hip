@@ -206,17 +206,10 @@ __global__ __launch_bounds__(256) void ln_finalize_kernel(const float* __restric
                                                           int M, int tiles, float inv_d) {
     const int m = blockIdx.x * 256 + threadIdx.x;
     if (m >= M) return;
-    const float* p = partials + (size_t)m * tiles * 2;
-    float s1 = 0.f;
-    for (int t = 0; t < tiles; ++t) s1 += p[2 * t];
-    const float mean = s1 * inv_d;
-    float m2 = 0.f;
-    for (int t = 0; t < tiles; ++t) {
-        const float d = p[2 * t] * (1.0f / 64.0f) - mean;
-        m2 += p[2 * t + 1] + 64.0f * d * d;
-    }
+    float mean, rstd;
+    ln_merge(partials + (size_t)m * tiles * 2, tiles, inv_d, mean, rstd);
     rowstat[2 * (size_t)m] = mean;
-    rowstat[2 * (size_t)m + 1] = rsqrtf(m2 * inv_d + 1e-6f);
+    rowstat[2 * (size_t)m + 1] = rstd;
 }
 
 hipError_t ln_finalize_launch(const float* partials, float* rowstat, int M, int tiles, int D, hipStream_t s) {

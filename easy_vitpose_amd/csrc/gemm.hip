@@ -581,7 +581,7 @@ __global__ __launch_bounds__(C::NT, 2) void gemm_kernel(GemmArgs g) {
             bias4[i] = (EPI == EPI_POS) ? f32x4{0.f, 0.f, 0.f, 0.f} : *(const f32x4*)(g.bias + n0 + wn * C::WN + i * 16 + fg * 4);
         // fused LayerNorm, consumer side: per-row (mean, rstd) of this lane's TJ fragment rows
         constexpr bool LN_CONSUMER = (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU);
-        const bool ln_in = LN_CONSUMER && g.rowstat != nullptr;
+        const bool ln_in = LN_CONSUMER && (g.rowstat != nullptr || g.ln_part != nullptr);
         // neutral defaults (mean 0, rstd 1: ln_fold(acc, 0, s, 1, b) == acc + b exactly), so that the arithmetic below is
         // unconditional straight-line code; only the LOADS sit behind the wave-uniform `ln_in` branch.  (A per-element
         // `if (ln_in)` around the fold compiled to a chain of scalar branches between the LDS staging writes, and that build
@@ -601,8 +601,12 @@ __global__ __launch_bounds__(C::NT, 2) void gemm_kernel(GemmArgs g) {
             for (int j = 0; j < C::TJ; ++j) {
                 int m = m0 + wm * C::WM + j * 16 + frow;
                 if (m > g.M - 1) m = g.M - 1;
-                ln_mean[j] = g.rowstat[2 * (size_t)m];
-                ln_rstd[j] = g.rowstat[2 * (size_t)m + 1];
+                if (g.ln_part) {
+                    ln_merge(g.ln_part + (size_t)m * g.ln_tiles * 2, g.ln_tiles, g.ln_inv_d, ln_mean[j], ln_rstd[j]);
+                } else {
+                    ln_mean[j] = g.rowstat[2 * (size_t)m];
+                    ln_rstd[j] = g.rowstat[2 * (size_t)m + 1];
+                }
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1032,7 +1036,12 @@ using Cfg8 = TileCfg<192, 128, 64, 96, 64, 2, 1, 0>;    //  80 KiB   4   (2 bloc
 using Cfg9 = TileCfg<64, 64, 64, 32, 32, 2, 0, 0>;      //  32 KiB   4   (5 blocks / CU)  small batches: enough tiles to fill 256 CUs
 using Cfg10 = TileCfg<192, 128, 64, 96, 64, 2, 5, 0>;   //  Cfg8 with the hand-scheduled (inline-asm ds_read, counted lgkmcnt) fragment pipeline
 using Cfg11 = TileCfg<192, 128, 64, 48, 64, 2, 1, 0>;  //  80 KiB   8   Cfg8 tile as 8 waves of 48x64 (4 waves / SIMD, 122 VGPRs)  <- default for the residual GEMMs
-static constexpr int NUM_TILE_CFGS = 12;
+// small batches (a few crops per GPU): the 2-stage ring waits for every k-block's full L2 latency; deeper rings keep 2-3 blocks in flight
+using Cfg12 = TileCfg<64, 64, 64, 32, 32, 4, 0, 0>;     //  64 KiB   4   (2 blocks / CU)  Cfg9 with a 4-stage ring
+using Cfg13 = TileCfg<128, 128, 64, 64, 64, 3, 1, 0>;   //  96 KiB   4   (1 block / CU)   Cfg1 with a 3-stage ring
+using Cfg14 = TileCfg<64, 64, 64, 32, 32, 3, 0, 0>;     //  48 KiB   4   (3 blocks / CU)  Cfg9 with a 3-stage ring
+using Cfg15 = TileCfg<128, 64, 64, 64, 32, 3, 0, 0>;    //  72 KiB   4   (2 blocks / CU)  128(m) x 64(n), 3-stage ring
+static constexpr int NUM_TILE_CFGS = 16;
 
 template <class T, int EPI, int AMODE, class C>
 static hipError_t launch(const GemmArgs& a, hipStream_t s) {
@@ -1071,6 +1080,10 @@ static hipError_t by_variant(const GemmArgs& a, hipStream_t s) {
         case 9: return launch<T, EPI, AMODE, Cfg9>(a, s);
         case 10: return launch<T, EPI, AMODE, Cfg10>(a, s);
         case 11: return launch<T, EPI, AMODE, Cfg11>(a, s);
+        case 12: return launch<T, EPI, AMODE, Cfg12>(a, s);
+        case 13: return launch<T, EPI, AMODE, Cfg13>(a, s);
+        case 14: return launch<T, EPI, AMODE, Cfg14>(a, s);
+        case 15: return launch<T, EPI, AMODE, Cfg15>(a, s);
     }
     return hipErrorInvalidValue;
 }
@@ -1091,7 +1104,8 @@ static hipError_t dispatch(int epi, const GemmArgs& a, hipStream_t s) {
 }
 
 int gemm_tile_bn(int variant) {
-    static const int bn[NUM_TILE_CFGS] = {Cfg0::BN, Cfg1::BN, Cfg2::BN, Cfg3::BN, Cfg4::BN, Cfg5::BN, Cfg6::BN, Cfg7::BN, Cfg8::BN, Cfg9::BN, Cfg10::BN, Cfg11::BN};
+    static const int bn[NUM_TILE_CFGS] = {Cfg0::BN, Cfg1::BN, Cfg2::BN, Cfg3::BN, Cfg4::BN, Cfg5::BN, Cfg6::BN, Cfg7::BN, Cfg8::BN, Cfg9::BN, Cfg10::BN, Cfg11::BN,
+                                          Cfg12::BN, Cfg13::BN, Cfg14::BN, Cfg15::BN};
     if (variant == 16 || variant == 19) return 256;
     if (variant == 17) return 192;
     return (variant >= 0 && variant < NUM_TILE_CFGS) ? bn[variant] : 0;

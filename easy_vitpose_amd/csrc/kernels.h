@@ -47,6 +47,11 @@ struct GemmArgs {
     // rowstat[m] = (mean, rstd), ln_s[n] = sum_k W'[n][k], bias[n] = sum_k beta_k W[n][k] + b[n]
     const float* rowstat;
     const float* ln_s;
+    // small batches: instead of rowstat, the producer's partial statistics [M][ln_tiles][2]; the consumer epilogue folds them itself
+    // (common.h::ln_merge, the same code ln_finalize_kernel runs) and the 2 x depth ln_finalize launches disappear
+    const float* ln_part;
+    int ln_tiles;
+    float ln_inv_d;       // 1 / D as the host computes it for ln_finalize_launch
     // 64x64-blocked activation layout [M/64][K/64][64][64]: every operand tile of the consuming GEMM is a run of
     // contiguous 8 KiB blocks (sequential DRAM bursts instead of 128-byte pieces at a row stride).  out_blocked: this
     // GEMM writes its 16-bit output that way (EPI_BIAS / EPI_BIAS_GELU, ldo == N); a_blocked: A is read that way.

@@ -101,6 +101,8 @@ struct vp_ctx {
     GraphEntry graphs[4];
     hipGraphExec_t graph_exec = nullptr;   // (unused placeholder kept for vp_destroy)
     int graph_max_n = 16;
+    int graph_max_n_stats = 0;        // experiment (VP_FOLD_STATS=1): batches <= 16 crops fold the LayerNorm statistics in the consumer GEMM's epilogue
+                                      // instead of 2 x depth ln_finalize launches -- bit-identical, measured SLOWER (L / 8 crops: 3.89 vs 2.97 ms per step)
     hipEvent_t ev_in = nullptr, ev_out = nullptr;   // vp_infer_device_stream: ordering against the caller's stream
     uint8_t* frame_stage = nullptr;   // device copy of the current video frame (vp_infer_frame)
     size_t frame_cap = 0;
@@ -337,6 +339,8 @@ struct LnFuse {
     float* stats_out = nullptr;       // producer: partial row statistics
     const float* rowstat = nullptr;   // consumer: (mean, rstd) per row
     const float* ln_s = nullptr;      // consumer: row sums of the folded weights
+    const float* ln_part = nullptr;   // consumer at small batch: the producer's partial statistics instead of rowstat
+    int ln_tiles = 0;
     int* tiles_out = nullptr;         // producer: number of n-tiles written per row
 };
 
@@ -361,7 +365,11 @@ int gemm(vp_ctx* c, int fam, int epi, const uint16_t* A, const uint16_t* W, cons
         const long par_ = (epi == vp::EPI_DECONV) ? 4 : 1;
         const long t192 = (long)((M + 191) / 192) * ((N + 127) / 128) * par_;
         const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128) * par_;
-        if (t192 < 384) { g.variant = (t128 >= 256) ? 1 : 9; g.group_m = 0; }
+        if (t192 < 384) {
+            g.variant = (t128 >= 256) ? 1 : 9; g.group_m = 0;
+            // long-K GEMMs on 64 x 64 tiles (fc2 of a few crops) are bound by the latency of every k-block: 4-stage ring (tools/gemm_small.py: -20 %)
+            if (g.variant == 9 && K >= 2048) g.variant = 12;
+        }
     }
     if (c->persist_gemm && g.variant == 8 && (epi == vp::EPI_BIAS || epi == vp::EPI_BIAS_GELU) && K % 128 == 0 && ldo == N &&
         M % 192 == 0 && N % 128 == 0 && (long)(M / 192) * (N / 128) >= 1024)   // >= 2 tiles per resident workgroup
@@ -369,6 +377,7 @@ int gemm(vp_ctx* c, int fam, int epi, const uint16_t* A, const uint16_t* W, cons
     if (ln) {
         g.a_blocked = ln->a_blocked; g.out_blocked = ln->out_blocked; g.reverse = ln->reverse;
         g.plane = ln->plane; g.stats_out = ln->stats_out; g.rowstat = ln->rowstat; g.ln_s = ln->ln_s;
+        g.ln_part = ln->ln_part; g.ln_tiles = ln->ln_tiles; g.ln_inv_d = 1.0f / (float)K;
         if (ln->tiles_out) *ln->tiles_out = N / 64;   // partial statistics are written per 64 columns, whatever the tile
     }
     // large batches: the 8-phase persistent kernel (gemm8.hip), one 512-thread workgroup per CU on 256 x 256 (wide GEMMs) or
@@ -390,6 +399,10 @@ int gemm(vp_ctx* c, int fam, int epi, const uint16_t* A, const uint16_t* W, cons
             g.persist = 0;
             g.stagger = c->g8_stagger;
         }
+    }
+    if (g.ln_part) {   // only the one-tile-per-workgroup 2-phase kernel folds partial statistics itself
+        g.persist = 0;
+        if (g.variant >= 16) { g.variant = 8; g.group_m = 8; }
     }
     const double par = (epi == vp::EPI_DECONV) ? 4.0 : 1.0;
     const double Nalg = (epi == vp::EPI_HEATMAP) ? (double)c->Kp : (double)N;   // heatmap: N counts the hi + lo weight rows
@@ -422,7 +435,10 @@ int forward_chunk(vp_ctx* c, const void* d_crops, int fmt, int n, bool want_toke
         uint16_t* xh = (uint16_t*)c->x;
         int tiles = 0;
         LnFuse prod; prod.plane = plane; prod.stats_out = c->ln_part; prod.tiles_out = &tiles;
+        // small batches: the consumers fold the partial statistics themselves (same code, same bits) -- 2 x depth launches less
+        const bool fold_stats = n <= c->graph_max_n_stats;
         auto finalize = [&]() -> int {
+            if (fold_stats) return VP_OK;
             LAUNCH(c, VP_PROF_LAYERNORM, 0.0, 8.0 * M * tiles + 8.0 * M, vp::ln_finalize_launch(c->ln_part, c->rowstat, M, tiles, D, c->stream));
             return VP_OK;
         };
@@ -431,6 +447,7 @@ int forward_chunk(vp_ctx* c, const void* d_crops, int fmt, int n, bool want_toke
         for (int l = 0; l < c->L; ++l) {
             const Block& b = c->blocks[l];
             LnFuse cq; cq.rowstat = c->rowstat; cq.ln_s = b.s_qkv; cq.reverse = (c->order_mask & 1) != 0;
+            if (fold_stats) { cq.rowstat = nullptr; cq.ln_part = c->ln_part; cq.ln_tiles = D / 64; }
             if ((rc = gemm(c, VP_PROF_GEMM_QKV, vp::EPI_BIAS, xh, b.w_qkv, b.b_qkv, c->qkv, nullptr, M, 3 * D, D, 3 * D, 0, 0, 0, &cq))) return rc;
             LAUNCH(c, VP_PROF_ATTN, 4.0 * 192 * 192 * (double)D * n, 8.0 * M * D,
                    vp::attention_launch(c->dtype, c->qkv, c->y, n, D, c->heads, c->stream));
@@ -438,6 +455,7 @@ int forward_chunk(vp_ctx* c, const void* d_crops, int fmt, int n, bool want_toke
             if ((rc = gemm(c, VP_PROF_GEMM_PROJ, vp::EPI_BIAS_RESID_LN, c->y, b.w_proj, b.b_proj, c->x, c->x, M, D, D, D, 0, 0, 0, &pp))) return rc;
             if ((rc = finalize())) return rc;
             LnFuse c1; c1.rowstat = c->rowstat; c1.ln_s = b.s_fc1; c1.out_blocked = c->blocked_hid; c1.reverse = (c->order_mask & 4) != 0;
+            if (fold_stats) { c1.rowstat = nullptr; c1.ln_part = c->ln_part; c1.ln_tiles = D / 64; }
             if ((rc = gemm(c, VP_PROF_GEMM_FC1, vp::EPI_BIAS_GELU, xh, b.w_fc1, b.b_fc1, c->hid, nullptr, M, 4 * D, D, 4 * D, 0, 0, 0, &c1))) return rc;
             LnFuse p2 = prod; p2.a_blocked = c->blocked_hid; p2.reverse = (c->order_mask & 8) != 0;
             if ((rc = gemm(c, VP_PROF_GEMM_FC2, vp::EPI_BIAS_RESID_LN, c->hid, b.w_fc2, b.b_fc2, c->x, c->x, M, D, 4 * D, D, 0, 0, 0, &p2))) return rc;
@@ -573,6 +591,7 @@ int vp_create(vp_handle* out, const vp_config* cfg) {
     if (const char* f = getenv("VP_GEMM8")) c->gemm8_mask = atoi(f);
     if (const char* f = getenv("VP_G8_STAGGER")) c->g8_stagger = atoi(f);
     if (const char* f = getenv("VP_GRAPH")) c->graph_max_n = atoi(f) != 0 ? 16 : 0;
+    if (const char* f = getenv("VP_FOLD_STATS")) c->graph_max_n_stats = atoi(f) != 0 ? 16 : 0;
     if (const char* f = getenv("VP_G8_DEFERRED")) c->g8_deferred = atoi(f) != 0;
     if (c->fuse_ln) {
         if ((rc = dalloc(c, &c->ln_part, M * (size_t)(D / 64) * 2))) return bail(rc);
