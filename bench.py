@@ -82,6 +82,18 @@ FAMILIES = {
 }
 
 
+def kernel_label(fam, T, B, shp):
+    """Name of the kernel a family runs on at this batch size.  The 8-phase kernel takes a GEMM when its row count is a multiple
+    of 256 and the launch has >= 512 output tiles (vitpose_api.hip: gemm()); smaller launches run gemm_kernel's tile table."""
+    pre, what = FAMILIES[fam]
+    if pre.startswith('gemm8'):
+        M = B * 192
+        ncols = {'gemm_fc1': 4 * shp.embed_dim // 256, 'gemm_qkv': 3 * shp.embed_dim // 256, 'gemm_fc2': shp.embed_dim // 192}[fam]
+        if M % 256 or (M // 256) * ncols < 512 or (fam == 'gemm_fc2' and shp.embed_dim % 192):
+            return f'gemm_kernel<{T}, ...> tile table (shape or launch size outside the 8-phase kernel's set): ' + what.split(',')[0]
+    return pre.format(T=T) + ' ...>: ' + what
+
+
 def pmc_traffic(args, fam):
     """HBM bytes per launch of a kernel family from the committed rocprofv3 PMC passes of THIS command (profiles/pmc_r2.json,
     made by tools/profile.sh + tools/summarize_profile.py; FETCH_SIZE x2 on gfx950 as MI355X_MICROARCH.md prescribes).
@@ -267,7 +279,7 @@ def main():
                        'gflop_per_person': round(shp.gflop_per_person(), 3)},
             'model_tflops': round(persons_s * shp.gflop_per_person() / 1e3, 1),
             'model_frac_of_mfma_peak': round(persons_s * shp.gflop_per_person() * 1e9 / PEAK_MFMA_16BIT, 4),
-            'roofline': {'bound': 'mfma', 'kernel': FAMILIES[dom][0].format(T=T) + ' ...>: ' + FAMILIES[dom][1],
+            'roofline': {'bound': 'mfma', 'kernel': kernel_label(dom, T, B, shp),
                          'achieved': round(ach / 1e12, 2), 'peak': PEAK_MFMA_16BIT / 1e12, 'unit': 'TFLOP/s',
                          'frac': round(ach / PEAK_MFMA_16BIT, 4), 'traffic': pmc_traffic(args, dom),
                          'launches': d['launches'], 'avg_launch_ms': round(d['ms'] / max(d['launches'], 1), 5),

@@ -99,6 +99,7 @@ struct vp_ctx {
     // replayed (170+ launches of a few microseconds each are launch-bound below ~16 crops); VP_GRAPH=0 disables
     struct GraphEntry { hipGraphExec_t exec = nullptr; int n = 0, fmt = -1, seen = 0; const void* src = nullptr; const int32_t* wh = nullptr; float* out = nullptr; };
     GraphEntry graphs[4];
+    int graph_victim = 0;
     hipGraphExec_t graph_exec = nullptr;   // (unused placeholder kept for vp_destroy)
     int graph_max_n = 16;
     int graph_max_n_stats = 0;        // experiment (VP_FOLD_STATS=1): batches <= 16 crops fold the LayerNorm statistics in the consumer GEMM's epilogue
@@ -509,8 +510,7 @@ int run_chunk(vp_ctx* c, const void* d_src, int fmt, int nb, const int32_t* d_wh
         return VP_OK;
     }
     if (!ge) {   // first sighting: run eagerly (also performs every one-time function-attribute set-up outside a capture), remember the key
-        static int victim = 0;
-        ge = &c->graphs[victim++ & 3];
+        ge = &c->graphs[c->graph_victim++ & 3];
         if (ge->exec) { hipGraphExecDestroy(ge->exec); ge->exec = nullptr; }
         ge->n = nb; ge->fmt = fmt; ge->src = d_src; ge->wh = d_wh; ge->out = d_out; ge->seen = 1;
         if ((rc = forward_chunk(c, d_src, fmt, nb, false))) return rc;
@@ -737,11 +737,12 @@ int vp_infer_submit(vp_handle c, const void* crops, int32_t fmt, int32_t n, cons
         char* q;
         if ((rc = dalloc(c, &q, (size_t)c->maxb * crop_bytes(VP_INPUT_F32_NCHW)))) return rc;
         sl.in = q;
-        if ((rc = dalloc(c, &sl.wh, (size_t)c->maxb * 2)) || (rc = dalloc(c, &sl.kp, (size_t)c->maxb * c->Kp * 3))) return rc;
-        HIPCHK(c, hipEventCreateWithFlags(&sl.h2d, hipEventDisableTiming));
-        HIPCHK(c, hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
-        HIPCHK(c, hipEventCreateWithFlags(&sl.out, hipEventDisableTiming));
     }
+    if (!sl.wh && (rc = dalloc(c, &sl.wh, (size_t)c->maxb * 2))) return rc;
+    if (!sl.kp && (rc = dalloc(c, &sl.kp, (size_t)c->maxb * c->Kp * 3))) return rc;
+    if (!sl.h2d) HIPCHK(c, hipEventCreateWithFlags(&sl.h2d, hipEventDisableTiming));
+    if (!sl.done) HIPCHK(c, hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+    if (!sl.out) HIPCHK(c, hipEventCreateWithFlags(&sl.out, hipEventDisableTiming));
     // copy stream: H2D of this call (the slot's previous D2H finished: vp_infer_wait was called on it)
     HIPCHK(c, hipMemcpyAsync(sl.in, crops, (size_t)n * crop_bytes(fmt), hipMemcpyHostToDevice, c->copy_stream));
     if (org_wh) HIPCHK(c, hipMemcpyAsync(sl.wh, org_wh, (size_t)n * 8, hipMemcpyHostToDevice, c->copy_stream));
@@ -971,6 +972,8 @@ static int group_run(vp_group* g, const void* crops, int32_t fmt, int32_t n, con
     for (int r0 = 0; r0 < n; r0 += per_round) {
         const int nr = n - r0 < per_round ? n - r0 : per_round;
         std::vector<int> slot(w, -1), offs(w, 0), cnts(w, 0);
+        // an error leaves no slot of any member in flight: every submitted shard is waited for before the error is returned
+        auto drain = [&](int from) { for (int i = from; i < w; ++i) if (slot[i] >= 0) { vp_infer_wait(g->h[i], slot[i]); slot[i] = -1; } };
         for (int i = 0; i < w; ++i) {
             int off, cnt;
             group_shard(nr, w, i, off, cnt);
@@ -978,21 +981,22 @@ static int group_run(vp_group* g, const void* crops, int32_t fmt, int32_t n, con
             if (cnt <= 0) continue;
             int rc = vp_infer_submit(g->h[i], (const char*)crops + (size_t)offs[i] * crop_bytes(fmt), fmt, cnt,
                                      org_wh ? org_wh + 2 * (size_t)offs[i] : nullptr, out + (size_t)offs[i] * K * 3, &slot[i]);
-            if (rc) { g->err = g->h[i]->err; return rc; }
+            if (rc) { g->err = g->h[i]->err; slot[i] = -1; drain(0); return rc; }
             if (d_all) {   // all-gather on the device side: this shard's keypoints to every device's copy, peer to peer, on the owner's stream
                 vp_ctx* c = g->h[i];
                 for (int j = 0; j < w; ++j) {
                     hipError_t e = hipMemcpyPeerAsync(d_all[j] + (size_t)offs[i] * K * 3, g->h[j]->cfg.device_id, c->slots[slot[i]].kp,
                                                       c->cfg.device_id, (size_t)cnt * K * 12, c->stream);
-                    if (e != hipSuccess) { g->err = std::string("hipMemcpyPeerAsync: ") + hipGetErrorString(e); return VP_ERR_HIP; }
+                    if (e != hipSuccess) { g->err = std::string("hipMemcpyPeerAsync: ") + hipGetErrorString(e); drain(0); return VP_ERR_HIP; }
                 }
             }
         }
         for (int i = 0; i < w; ++i)
             if (slot[i] >= 0) {
                 int rc = vp_infer_wait(g->h[i], slot[i]);
+                slot[i] = -1;
                 if (!rc && d_all) rc = vp_synchronize(g->h[i]);
-                if (rc) { g->err = g->h[i]->err; return rc; }
+                if (rc) { g->err = g->h[i]->err; drain(i + 1); return rc; }
             }
     }
     return VP_OK;
