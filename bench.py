@@ -90,8 +90,51 @@ def kernel_label(fam, T, B, shp):
         M = B * 192
         ncols = {'gemm_fc1': 4 * shp.embed_dim // 256, 'gemm_qkv': 3 * shp.embed_dim // 256, 'gemm_fc2': shp.embed_dim // 192}[fam]
         if M % 256 or (M // 256) * ncols < 512 or (fam == 'gemm_fc2' and shp.embed_dim % 192):
-            return f'gemm_kernel<{T}, ...> tile table (shape or launch size outside the 8-phase kernel's set): ' + what.split(',')[0]
+            return f'gemm_kernel<{T}, ...> tile table (shape or launch size outside the set of the 8-phase kernel): ' + what.split(',')[0]
     return pre.format(T=T) + ' ...>: ' + what
+
+
+def strong_scaling_config4(world, rank, dev, dtype, steps=100, warmup=10):
+    """BASELINE.json configs[3]: one frame of 64 crops through ViTPose-L coco_25, strong-scaled: every rank takes 64 / world crops
+    (resident in its HBM), RCCL all-gather of the keypoints, max-over-ranks time.  Reported inside the single JSON line as
+    `strong_scaling_config4` (the driver computes efficiency from the per-N values)."""
+    import torch
+    import torch.distributed as dist
+    from easy_vitpose_amd import VitPoseHip
+    from easy_vitpose_amd.configs import model_shape
+    from easy_vitpose_amd.parallel import shard_bounds
+    from easy_vitpose_amd.synth import synthetic_crops, synthetic_state_dict
+    shp = model_shape('l', 'coco_25')
+    N, K = 64, shp.num_keypoints
+    lo, hi = shard_bounds(N, world, rank)
+    per = -(-N // world)
+    eng = VitPoseHip(shp, synthetic_state_dict(shp, 0), dtype=dtype, device_id=dev.index, max_batch=per)
+    crops = torch.from_numpy(synthetic_crops(N, seed=4, kind='noise')[lo:hi]).to(dev)
+    local = torch.zeros((per, K, 3), dtype=torch.float32, device=dev)
+    gathered = torch.zeros((world * per, K, 3), dtype=torch.float32, device=dev)
+
+    def frame():
+        if hi > lo:
+            eng.infer_device(crops, local[:hi - lo], sync=True)
+        dist.all_gather_into_tensor(gathered, local)
+
+    def fence():
+        eng.synchronize(); torch.cuda.synchronize(); dist.barrier()
+
+    for _ in range(warmup):
+        frame()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        frame()
+    fence()
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    eng.close()
+    dt = float(t.item())
+    return {'workload': 'ViTPose-L coco_25, one frame of 64 u8 crops resident in HBM, 64/world per rank, RCCL all-gather of keypoints',
+            'scaling': 'strong', 'crops_per_rank': per, 'frames': steps, 'ms_per_frame': round(dt / steps * 1e3, 4),
+            'persons_per_sec': round(N * steps / dt, 1)}
 
 
 def pmc_traffic(args, fam):
@@ -161,6 +204,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-host-path', action='store_true')
     ap.add_argument('--breakdown', action='store_true', help='extra untimed pass with every kernel family timed (stderr)')
+    ap.add_argument('--strong', action='store_true', help='also measure the strong-scaled frame of BASELINE configs[3] (default when WORLD_SIZE > 1)')
     ap.add_argument('--force-dist', action='store_true', help='run the RCCL code path (process group, all-gather, barrier) even with one rank')
     args = ap.parse_args()
 
@@ -248,6 +292,10 @@ def main():
     if rank == 0 and world == 1 and not args.no_host_path:
         host_rate = host_path_rate(eng, crops_u8, K)
 
+    strong = None
+    if use_dist and (world > 1 or args.strong):
+        strong = strong_scaling_config4(world, rank, dev, args.dtype)
+
     breakdown = None
     if args.breakdown and rank == 0:
         eng.set_profiling(True); eng.reset_profile()
@@ -290,6 +338,8 @@ def main():
                         'p90': round(float(np.percentile(step_ms, 90)), 4), 'n': len(step_ms), 'note': 'one host synchronisation per step'},
             'host_persons_per_sec': None if host_rate is None else round(host_rate, 1),
         }
+        if strong is not None:
+            line['strong_scaling_config4'] = strong
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(args.variant, args.dataset)
         else:
