@@ -450,7 +450,96 @@ __global__ __launch_bounds__(C::NT, 2) void gemm_kernel(GemmArgs g) {
     // stride: measured 1.2-1.7 TB/s.  Instead the C tile goes through the (now idle) LDS ring in passes
     // of JP row-tiles per wave and leaves as whole-row 16-byte-per-lane accesses (a wave instruction =
     // 1 KiB of consecutive output bytes); the fp32 residual / pos operand is read the same way.
-    if constexpr (LN_PROD && !C::DIRECT) {
+    if constexpr (EPI == EPI_DECONV_FINAL) {
+        // deconv2 + folded BN + ReLU with the final 1x1 conv fused behind it (topdown_heatmap_simple_head.py:188-193): the tile
+        // holds ALL 256 channels of its 256 output pixels, so the 16-bit activations go to LDS instead of HBM (the [B,64,48,256]
+        // tensor, 402 MB at batch 256, is never written or read) and a second small MFMA product with the hi + lo final-layer
+        // weights (vitpose_api.hip upload_final: [16 hi rows][16 lo rows] groups) gives the heatmaps.  Arithmetic and
+        // accumulation order are those of EPI_DECONV followed by EPI_HEATMAP (k ascending in steps of 32, hi and lo products
+        // in separate accumulators, hi + lo, + bias): bit-identical heatmaps -- tests/test_gpu_gemm_cfgs.py, test_gpu_api.py.
+        static_assert(C::BN == 256 && C::BM % (C::NWAVES * 16) == 0, "the fused head needs all 256 channels in one tile");
+        constexpr int RB = C::BN * 2 + 16;                 // staged row: 256 channels x 16 bit + 16 B (conflict-free fragment reads)
+        constexpr int RPW = C::BM / C::NWAVES, JW = RPW / 16;   // rows / 16-row fragments of the second product per wave
+        f32x4 bias4[C::TI];
+#pragma unroll
+        for (int i = 0; i < C::TI; ++i) bias4[i] = *(const f32x4*)(g.bias + wn * C::WN + i * 16 + fg * 4);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();   // every wave is done with the operand ring
+#pragma unroll
+        for (int j = 0; j < C::TJ; ++j) {
+            char* lrow = smem + (wm * C::WM + j * 16 + frow) * RB + (wn * C::WN + fg * 4) * 2;
+#pragma unroll
+            for (int i = 0; i < C::TI; ++i) {
+                f32x4 v = acc[i][j] + bias4[i];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+                u32x2 o;
+                o[0] = pack2<T>(v[0], v[1]);
+                o[1] = pack2<T>(v[2], v[3]);
+                *(u32x2*)(lrow + i * 32) = o;
+            }
+        }
+        // second product: wave w owns tile rows [w RPW, (w + 1) RPW); B fragments (pixels x 32 channels) from LDS, A fragments
+        // (16 hi or lo weight rows x 32 channels) straight from L2 (the whole operand is 32 * ceil(Kp / 16) * 512 bytes).  The
+        // weight fragments of a 16-joint group are fetched one group ahead (the first before the barrier that publishes the
+        // staged tile: the accumulators are dead by then), so only one L2 round trip is exposed per tile.
+        const int groups = (g.Kp + 15) >> 4;
+        auto ldw = [&](u32x4(&w)[16], int u) {
+            const uint16_t* wrow = g.W2 + (size_t)(u * 32 + frow) * C::BN + fg * 8;
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                w[2 * ks] = *(const u32x4*)(wrow + ks * 32);
+                w[2 * ks + 1] = *(const u32x4*)(wrow + 16 * C::BN + ks * 32);
+            }
+        };
+        u32x4 wA[16], wB[16];
+        ldw(wA, 0);
+        __syncthreads();
+        u32x4 bf[JW][8];
+#pragma unroll
+        for (int jj = 0; jj < JW; ++jj)
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) bf[jj][ks] = *(const u32x4*)(smem + (wave * RPW + jj * 16 + frow) * RB + (ks * 32 + fg * 8) * 2);
+        size_t orow[JW];
+        bool live[JW];
+        const int opix = 4 * g.Hin * g.Win;
+#pragma unroll
+        for (int jj = 0; jj < JW; ++jj) {
+            const int m = m0 + wave * RPW + jj * 16 + frow;
+            live[jj] = m < g.M && !(g.ablate & 8);
+            const int t = m / g.Win, jx = m - t * g.Win, ii = t % g.Hin, img = t / g.Hin;
+            orow[jj] = (size_t)img * g.Kp * opix + (size_t)(2 * ii + (parity >> 1)) * (2 * g.Win) + 2 * jx + (parity & 1);
+        }
+        auto group = [&](const u32x4(&w)[16], int u) {
+            f32x4 ah[JW], al[JW];
+            const int nb = u * 16 + fg * 4;
+            const f32x4 b2 = *(const f32x4*)(g.bias2 + nb);   // padded to a multiple of 256 floats at upload
+#pragma unroll
+            for (int jj = 0; jj < JW; ++jj) { ah[jj] = f32x4{0.f, 0.f, 0.f, 0.f}; al[jj] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+                for (int jj = 0; jj < JW; ++jj) {
+                    ah[jj] = mfma16<T>(w[2 * ks], bf[jj][ks], ah[jj]);
+                    al[jj] = mfma16<T>(w[2 * ks + 1], bf[jj][ks], al[jj]);
+                }
+#pragma unroll
+            for (int jj = 0; jj < JW; ++jj) {
+                const f32x4 v = ah[jj] + al[jj];
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (live[jj] && nb + r < g.Kp) g.out2[orow[jj] + (size_t)(nb + r) * opix] = v[r] + b2[r];
+            }
+        };
+        for (int u = 0; u < groups; u += 2) {
+            if (u + 1 < groups) ldw(wB, u + 1);
+            group(wA, u);
+            if (u + 1 < groups) {
+                if (u + 2 < groups) ldw(wA, u + 2);
+                group(wB, u + 1);
+            }
+        }
+    } else if constexpr (LN_PROD && !C::DIRECT) {
         // Fused-LayerNorm producer (patch embed, attn.proj, mlp.fc2).  The residual stream lives in HBM as two
         // 16-bit planes, x = hi + lo with hi = round16(x), lo = round16(x - hi): the same 4 bytes per element as
         // fp32 (>= 22 significant bits), but the hi plane IS the un-normalised 16-bit operand the next qkv / fc1
@@ -1047,11 +1136,14 @@ template <class T, int EPI, int AMODE, class C>
 static hipError_t launch(const GemmArgs& a, hipStream_t s) {
     if constexpr ((EPI == EPI_BIAS_RESID_LN || EPI == EPI_POS_LN) && C::DIRECT) return hipErrorInvalidValue;
     auto kern = gemm_kernel<T, EPI, AMODE, C>;
+    // fused head: the staged 16-bit tile [BM][BN + 8] may be larger than the operand ring
+    constexpr int LDS_BYTES = (EPI == EPI_DECONV_FINAL && C::BM * (C::BN * 2 + 16) > C::LDS) ? C::BM * (C::BN * 2 + 16) : C::LDS;
+    static_assert(LDS_BYTES <= 160 * 1024, "LDS");
     static bool attr_done[64] = {};   // the > 64 KiB LDS opt-in is a per-device function attribute
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (dev < 0 || dev >= 64 || !attr_done[dev]) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         if (e != hipSuccess) return e;
         if (dev >= 0 && dev < 64) attr_done[dev] = true;
     }
@@ -1061,7 +1153,7 @@ static hipError_t launch(const GemmArgs& a, hipStream_t s) {
     if ((size_t)tiles_n * C::BN > (size_t)a.w_rows) return hipErrorInvalidValue;   // weight rows are padded at upload
     const int tiles = ((a.M + C::BM - 1) / C::BM) * tiles_n;
     dim3 grid(tiles, AMODE == A_DECONV ? 4 : 1);
-    hipLaunchKernelGGL(kern, grid, dim3(C::NT), C::LDS, s, g);
+    hipLaunchKernelGGL(kern, grid, dim3(C::NT), LDS_BYTES, s, g);
     return hipGetLastError();
 }
 
@@ -1099,6 +1191,9 @@ static hipError_t dispatch(int epi, const GemmArgs& a, hipStream_t s) {
         case EPI_HEATMAP: return by_variant<T, EPI_HEATMAP, A_DENSE>(a, s);
         case EPI_BIAS_RESID_LN: return by_variant<T, EPI_BIAS_RESID_LN, A_DENSE>(a, s);
         case EPI_POS_LN: return by_variant<T, EPI_POS_LN, A_DENSE>(a, s);
+        case EPI_DECONV_FINAL:   // one tile configuration: 256 x 256 (all channels of a pixel in one tile)
+            if (a.variant != 3 || a.N != Cfg3::BN || !a.W2 || !a.bias2 || !a.out2 || a.Kp <= 0) return hipErrorInvalidValue;
+            return launch<T, EPI_DECONV_FINAL, A_DECONV, Cfg3>(a, s);
     }
     return hipErrorInvalidValue;
 }
@@ -1129,7 +1224,7 @@ hipError_t gemm_launch(int dtype, int epi, const GemmArgs& a, hipStream_t s) {
             return epi == EPI_BIAS ? launch_persist<F16, EPI_BIAS, Cfg8>(a, s) : launch_persist<F16, EPI_BIAS_GELU, Cfg8>(a, s);
         return epi == EPI_BIAS ? launch_persist<BF16, EPI_BIAS, Cfg8>(a, s) : launch_persist<BF16, EPI_BIAS_GELU, Cfg8>(a, s);
     }
-    if (a.a_blocked && (epi == EPI_DECONV || (a.M & 63))) return hipErrorInvalidValue;
+    if (a.a_blocked && (epi == EPI_DECONV || epi == EPI_DECONV_FINAL || (a.M & 63))) return hipErrorInvalidValue;
     if (a.out_blocked && ((epi != EPI_BIAS && epi != EPI_BIAS_GELU) || (a.M & 63) || (a.N & 63) || a.ldo != a.N)) return hipErrorInvalidValue;
     if ((epi == EPI_BIAS_RESID_LN || epi == EPI_POS_LN) && (a.N % 64 != 0 || !a.plane || !a.stats_out)) return hipErrorInvalidValue;
     return dtype == DT_F16 ? dispatch<F16>(epi, a, s) : dispatch<BF16>(epi, a, s);

@@ -19,6 +19,8 @@ enum GemmEpi {
     EPI_HEATMAP = 5,     // + bias            -> fp32 NCHW heatmaps [B, Kp, 64*48]  (final 1x1 conv)
     EPI_BIAS_RESID_LN = 6,  // EPI_BIAS_RESID on the two-plane residual stream + fused-LayerNorm row statistics
     EPI_POS_LN = 7,         // EPI_POS        writing the two-plane residual stream + row statistics
+    EPI_DECONV_FINAL = 8,   // EPI_DECONV with the final 1x1 conv (EPI_HEATMAP) fused behind it: the 256-channel activations stay in LDS,
+                            // fp32 NCHW heatmaps at out2 (256 x 256 tile only: N == 256, variant 3)
 };
 enum GemmAMode { A_DENSE = 0, A_DECONV = 1 };
 
@@ -32,6 +34,10 @@ struct GemmArgs {
     int Hin, Win, Cin;    // deconv geometry (K = 4 * Cin)
     const uint16_t* zero; // >= 128 B of zeros (deconv border taps)
     int Kp;               // heatmap: number of keypoints (== N)
+    // EPI_DECONV_FINAL: final-layer weights as [16 hi][16 lo] row groups x 256 channels, bias [Kp], heatmaps fp32 [B, Kp, 2Hin, 2Win]
+    const uint16_t* W2;
+    const float* bias2;
+    float* out2;
     int w_rows;           // rows W is padded to at upload (multiple of 256); deconv parity slab = w_rows * K
     int variant;          // tile configuration (gemm.hip Cfg0..)
     int group_m;          // grouped tile order: m-tiles per group (<= 1: plain n-fastest order)

@@ -100,6 +100,7 @@ struct vp_ctx {
     struct GraphEntry { hipGraphExec_t exec = nullptr; int n = 0, fmt = -1, seen = 0; const void* src = nullptr; const int32_t* wh = nullptr; float* out = nullptr; };
     GraphEntry graphs[4];
     int graph_victim = 0;
+    bool fuse_head = true;            // VP_FUSE_HEAD=0: deconv2 and the final 1x1 conv as two launches at every batch size
     hipGraphExec_t graph_exec = nullptr;   // (unused placeholder kept for vp_destroy)
     int graph_max_n = 16;
     int graph_max_n_stats = 0;        // experiment (VP_FOLD_STATS=1): batches <= 16 crops fold the LayerNorm statistics in the consumer GEMM's epilogue
@@ -401,18 +402,27 @@ int gemm(vp_ctx* c, int fam, int epi, const uint16_t* A, const uint16_t* W, cons
             g.stagger = c->g8_stagger;
         }
     }
+    if (epi == vp::EPI_DECONV_FINAL) {   // deconv2 + final 1x1 conv in one kernel: the 256 x 256 tile (all channels of a pixel)
+        g.variant = 3; g.group_m = 0; g.persist = 0;
+        g.W2 = c->w_fin; g.bias2 = c->b_fin; g.out2 = c->hm;
+    }
     if (g.ln_part) {   // only the one-tile-per-workgroup 2-phase kernel folds partial statistics itself
         g.persist = 0;
         if (g.variant >= 16) { g.variant = 8; g.group_m = 8; }
     }
-    const double par = (epi == vp::EPI_DECONV) ? 4.0 : 1.0;
+    const bool deconv = epi == vp::EPI_DECONV || epi == vp::EPI_DECONV_FINAL;
+    const double par = deconv ? 4.0 : 1.0;
     const double Nalg = (epi == vp::EPI_HEATMAP) ? (double)c->Kp : (double)N;   // heatmap: N counts the hi + lo weight rows
-    const double flops = 2.0 * M * Nalg * K * par;
+    double flops = 2.0 * M * Nalg * K * par;
     // algorithmic HBM bytes: each operand once, output once (+ residual read)
     const bool resid = epi == vp::EPI_BIAS_RESID || epi == vp::EPI_BIAS_RESID_LN;
     const bool f32out = resid || epi == vp::EPI_POS || epi == vp::EPI_POS_LN || epi == vp::EPI_HEATMAP;
     const double out_b = f32out ? 4.0 : 2.0;
-    double bytes = 2.0 * M * (double)(epi == vp::EPI_DECONV ? Cin : K) + 2.0 * N * (double)K * par + out_b * M * Nalg * par;
+    double bytes = 2.0 * M * (double)(deconv ? Cin : K) + 2.0 * N * (double)K * par + out_b * M * Nalg * par;
+    if (epi == vp::EPI_DECONV_FINAL) {   // the 256-channel activations never reach HBM; the final conv's flops and the fp32 heatmaps count
+        flops += 2.0 * M * par * (double)c->Kp * N;
+        bytes += (4.0 * c->Kp - out_b * N) * M * par + 2.0 * c->fin_rows * N;
+    }
     if (resid) bytes += 4.0 * M * (double)N;
     if (epi == vp::EPI_BIAS_RESID_LN || epi == vp::EPI_POS_LN) bytes += 8.0 * M * (double)(N / 64);   // partial row statistics
     LAUNCH(c, fam, flops, bytes, vp::gemm_launch(c->dtype, epi, g, c->stream));
@@ -482,6 +492,10 @@ int forward_chunk(vp_ctx* c, const void* d_crops, int fmt, int n, bool want_toke
            vp::layernorm_launch(c->dtype, c->x, c->lnf_g, c->lnf_b, c->y, want_tokens ? c->tok : nullptr, M, D, c->stream, plane));
     // head: tokens [n,16,12,D] (NHWC view of [n*192, D]) -> [n,32,24,256] -> [n,64,48,256] -> heatmaps [n,Kp,64,48]
     if ((rc = gemm(c, VP_PROF_GEMM_DECONV, vp::EPI_DECONV, c->y, c->w_d1, c->b_d1, c->d1, nullptr, n * 192, 256, 4 * D, 256, 16, 12, D))) return rc;
+    // large batches: the final 1x1 conv rides in deconv2's epilogue (gemm.hip EPI_DECONV_FINAL, bit-identical heatmaps) and the
+    // [n,64,48,256] tensor is never written; small batches keep the two launches on tiles that still fill 256 CUs
+    if (c->fuse_head && c->gemm_variant[VP_PROF_GEMM_DECONV] < 0 && (long)n * 12 >= 512)
+        return gemm(c, VP_PROF_GEMM_DECONV, vp::EPI_DECONV_FINAL, c->d1, c->w_d2, c->b_d2, nullptr, nullptr, n * 768, 256, 1024, 256, 32, 24, 256);
     if ((rc = gemm(c, VP_PROF_GEMM_DECONV, vp::EPI_DECONV, c->d1, c->w_d2, c->b_d2, c->d2, nullptr, n * 768, 256, 1024, 256, 32, 24, 256))) return rc;
     if ((rc = gemm(c, VP_PROF_GEMM_FINAL, vp::EPI_HEATMAP, c->d2, c->w_fin, c->b_fin, c->hm, nullptr, n * 3072, (int)c->fin_rows, 256, 0))) return rc;
     return VP_OK;
@@ -591,6 +605,7 @@ int vp_create(vp_handle* out, const vp_config* cfg) {
     if (const char* f = getenv("VP_GEMM8")) c->gemm8_mask = atoi(f);
     if (const char* f = getenv("VP_G8_STAGGER")) c->g8_stagger = atoi(f);
     if (const char* f = getenv("VP_GRAPH")) c->graph_max_n = atoi(f) != 0 ? 16 : 0;
+    if (const char* f = getenv("VP_FUSE_HEAD")) c->fuse_head = atoi(f) != 0;
     if (const char* f = getenv("VP_FOLD_STATS")) c->graph_max_n_stats = atoi(f) != 0 ? 16 : 0;
     if (const char* f = getenv("VP_G8_DEFERRED")) c->g8_deferred = atoi(f) != 0;
     if (c->fuse_ln) {

@@ -89,6 +89,29 @@ def test_small_batch_graph_replay_is_bit_identical(monkeypatch):
     assert not np.array_equal(o2, ref)
 
 
+@pytest.mark.parametrize('variant,dataset,dtype,n', [('s', 'coco', 'fp16', 64), ('s', 'wholebody', 'fp16', 48), ('b', 'coco_25', 'bf16', 44)])
+def test_fused_head_is_bit_identical(monkeypatch, variant, dataset, dtype, n):
+    """Batches of >= 43 crops run deconv2 + final 1x1 conv as ONE kernel (gemm.hip EPI_DECONV_FINAL: the 256-channel activations
+    stay in LDS).  Same arithmetic, same accumulation order as the two launches: heatmaps and keypoints must agree bit for bit
+    (K = 17, 25 and 133: one, two and nine 16-joint weight groups; topdown_heatmap_simple_head.py:188-193)."""
+    shp, sd, _ = weights(variant, dataset)
+    crops = synthetic_crops(n, 21, 'blobs')
+    monkeypatch.setenv('VP_FUSE_HEAD', '0')
+    eng = VitPoseHip(shp, sd, dtype=dtype, max_batch=n)
+    ref_kp, ref_hm = eng.infer(crops), eng.heatmaps(crops)
+    eng.close()
+    monkeypatch.setenv('VP_FUSE_HEAD', '1')
+    eng = VitPoseHip(shp, sd, dtype=dtype, max_batch=n)
+    eng.set_profiling(True)
+    kp, hm = eng.infer(crops), eng.heatmaps(crops)
+    prof = eng.profile()
+    eng.close()
+    assert prof['gemm_final']['launches'] == 0 and prof['gemm_deconv']['launches'] == 4, 'the fused kernel did not run'
+    assert np.array_equal(hm, ref_hm)
+    assert np.array_equal(kp, ref_kp)
+    assert np.isfinite(hm).all() and float(np.abs(hm).max()) > 0
+
+
 def test_group_matches_single_handle():
     """vp_group_* with every visible device (1 on the test box): sharded result == unsharded result, bit for bit; the
     device-side all-gather leaves all keypoints on every member."""
