@@ -294,7 +294,66 @@ __global__ __launch_bounds__(256) void peak_glds_kernel(const char* __restrict__
     if (iters < 0) sink[threadIdx.x] = ((float*)smem)[threadIdx.x];
 }
 
+// Issue-interplay probe (tools/issue_probe.py): every wave runs `iters` rounds of 16 independent MFMAs (256 matrix-pipe cycles)
+// and, per round, optionally (mode bit 0) ONE 16-byte-per-lane global store to a streaming address, (bit 1) ONE 1 KiB LDS-DMA
+// load with 8 kept in flight, (bit 2) 48 independent VALU FMAs, (bit 3) 4 stores instead of 1.  NW waves per workgroup, one
+// workgroup per CU: NW = 4 -> one wave per SIMD, NW = 8 -> two.  What a store / DMA / VALU block costs a wave whose matrix
+// pipe is otherwise saturated is the difference to mode 0.
+template <int NW, int mode>
+__global__ __launch_bounds__(NW * 64, 1) void issue_probe_kernel(int iters, char* __restrict__ dst, const char* __restrict__ src,
+                                                                 size_t mask, float* sink) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    u32x4 a = {0x3c003c00u + threadIdx.x, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u};
+    u32x4 b = {0x38003800u, 0x38003800u + threadIdx.x, 0x38003800u, 0x38003800u};
+    f32x4 acc[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float f[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) f[i] = 1.0f + 0.001f * (float)(lane + i);
+    size_t off = ((size_t)(blockIdx.x * NW + wave) * 1024 * 64) & mask;
+    u32x4 data = {(uint32_t)lane, 1u, 2u, 3u};
+    if (mode & 2) {
+#pragma unroll
+        for (int d = 0; d < 8; ++d) glds16(src + ((off + d * 1024) & mask) + lane * 16, smem + ((wave * 8 + d) & 127) * 1024);
+    }
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            acc[i] = mfma16<F16>(a, b, acc[i]);
+            if (mode & 4) {
+#pragma unroll
+                for (int q = 0; q < 3; ++q) f[(i * 3 + q) & 7] = fmaf(f[(i * 3 + q) & 7], 1.0001f, 0.5f);
+            }
+            if (i == 3 && (mode & 1)) {
+                *(u32x4*)(dst + off + lane * 16) = data;
+                if (mode & 8) {
+                    *(u32x4*)(dst + ((off + 1024) & mask) + lane * 16) = data;
+                    *(u32x4*)(dst + ((off + 2048) & mask) + lane * 16) = data;
+                    *(u32x4*)(dst + ((off + 3072) & mask) + lane * 16) = data;
+                }
+            }
+            if (i == 9 && (mode & 2)) {
+                glds16(src + off + lane * 16, smem + ((wave * 8 + (it & 7)) & 127) * 1024);
+                asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+            }
+        }
+        off = (off + 4096) & mask;
+        data[1] += 1u;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    f32x4 s4 = acc[0];
+#pragma unroll
+    for (int i = 1; i < 16; ++i) s4 += acc[i];
+    float fs = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) fs += f[i];
+    if (s4[0] + fs == 12345.f) sink[threadIdx.x] = s4[1] + ((float*)smem)[threadIdx.x];
+}
+
 // kind 0: MFMA 16x16x32 f16, 1: MFMA 32x32x16 f16 (returns TFLOP/s); 2: float4 copy (returns TB/s read+write);
+// 100 + mode (+ 32: two waves per SIMD; mode bit 4: 1 MiB = L2-resident buffers): issue probe, returns nanoseconds per round
 // 3 / 4 / 5 / 6: LDS-DMA stream from a 32 MiB / 1 GiB / 2 MiB / 256 KiB source, 2 blocks per CU (TB/s into LDS)
 hipError_t peak_bench(int kind, double* result) {
     hipEvent_t e0, e1;
@@ -315,6 +374,35 @@ hipError_t peak_bench(int kind, double* result) {
         const double flops = (double)blocks * 4 * iters * (kind == 0 ? 16.0 * 16384 : 4.0 * 32768);
         *result = flops / (ms * 1e-3) / 1e12;
         hipFree(d);
+    } else if (kind >= 100 && kind < 164) {
+        const int mode = (kind - 100) & 31, nw = (kind - 100) & 32 ? 8 : 4;
+        const size_t bytes = (mode & 16) ? ((size_t)1 << 20) : ((size_t)256 << 20);   // bit 4: all traffic inside 1 MiB (L2-resident)
+        char *dst, *src; float* d;
+        hipMalloc(&dst, bytes + 8192); hipMalloc(&src, bytes + 8192); hipMalloc(&d, 4096);
+        hipMemset(src, 1, bytes + 8192);
+        const int iters = 8000;
+        hipError_t (*run)(int, int, char*, const char*, size_t, float*) = nullptr;
+        switch (mode & 15) {
+#define VP_PROBE(M) case M: run = [](int nw_, int it_, char* d_, const char* s_, size_t m_, float* k_) -> hipError_t { \
+                if (nw_ == 4) { auto k = issue_probe_kernel<4, M>; hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 131072); \
+                    hipLaunchKernelGGL(k, dim3(256), dim3(256), 131072, nullptr, it_, d_, s_, m_, k_); } \
+                else { auto k = issue_probe_kernel<8, M>; hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 131072); \
+                    hipLaunchKernelGGL(k, dim3(256), dim3(512), 131072, nullptr, it_, d_, s_, m_, k_); } \
+                return hipGetLastError(); }; break;
+            VP_PROBE(0) VP_PROBE(1) VP_PROBE(2) VP_PROBE(3) VP_PROBE(4) VP_PROBE(5) VP_PROBE(6) VP_PROBE(7)
+            VP_PROBE(9) VP_PROBE(11) VP_PROBE(13) VP_PROBE(15)
+#undef VP_PROBE
+        }
+        if (!run) { hipFree(dst); hipFree(src); hipFree(d); hipEventDestroy(e0); hipEventDestroy(e1); return hipErrorInvalidValue; }
+        for (int rep = 0; rep < 2; ++rep) {
+            hipEventRecord(e0, nullptr);
+            run(nw, iters, dst, src, bytes - 1, d);
+            hipEventRecord(e1, nullptr);
+            hipDeviceSynchronize();
+        }
+        hipEventElapsedTime(&ms, e0, e1);
+        *result = (double)ms * 1e6 / iters;
+        hipFree(dst); hipFree(src); hipFree(d);
     } else if (kind >= 3 && kind <= 6) {
         const size_t bytes = kind == 3 ? ((size_t)32 << 20) : kind == 4 ? ((size_t)1 << 30) : kind == 5 ? ((size_t)2 << 20) : ((size_t)256 << 10);
         char* a; float* d;
