@@ -88,8 +88,12 @@ def kernel_label(fam, T, B, shp):
     pre, what = FAMILIES[fam]
     if pre.startswith('gemm8'):
         M = B * 192
-        ncols = {'gemm_fc1': 4 * shp.embed_dim // 256, 'gemm_qkv': 3 * shp.embed_dim // 256, 'gemm_fc2': shp.embed_dim // 192}[fam]
-        if M % 256 or (M // 256) * ncols < 512 or (fam == 'gemm_fc2' and shp.embed_dim % 192):
+        D = shp.embed_dim
+        bn2 = 192 if D % 192 == 0 else 256          # residual GEMMs: 256 x 192 tiles when N = D divides, else 256 x 256
+        ncols = {'gemm_fc1': 4 * D // 256, 'gemm_qkv': 3 * D // 256, 'gemm_fc2': D // bn2}[fam]
+        if fam == 'gemm_fc2' and bn2 == 256:
+            what = what.replace('256x192', '256x256')
+        if M % 256 or (M // 256) * ncols < 512 or (fam == 'gemm_fc2' and D % bn2):
             return f'gemm_kernel<{T}, ...> tile table (shape or launch size outside the set of the 8-phase kernel): ' + what.split(',')[0]
     return pre.format(T=T) + ' ...>: ' + what
 
@@ -194,7 +198,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=100)
-    ap.add_argument('--warmup', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=20)
     ap.add_argument('--dtype', default='fp16', choices=['fp16', 'bf16'])
     ap.add_argument('--batch', type=int, default=256)
     ap.add_argument('--max-batch', type=int, default=0, help='workspace batch of the handle (< --batch: the batch is processed in chunks)')

@@ -93,7 +93,8 @@ struct vp_ctx {
     // H2D of call i+1 and the D2H of call i-1 run on the copy stream under the compute of call i
     struct Slot { void* in = nullptr; int32_t* wh = nullptr; float* kp = nullptr; hipEvent_t h2d = nullptr, done = nullptr, out = nullptr; bool busy = false; };
     Slot slots[2];
-    hipStream_t copy_stream = nullptr;
+    hipStream_t copy_stream = nullptr;   // H2D of the asynchronous path
+    hipStream_t d2h_stream = nullptr;    // D2H on its own stream: an in-order copy stream would hold the next upload behind `wait compute; download`
     int next_slot = 0;
     // small batches: the whole forward + decode of a chunk captured once per (n, input format, source pointer) into a hipGraph and
     // replayed (170+ launches of a few microseconds each are launch-bound below ~16 crops); VP_GRAPH=0 disables
@@ -745,6 +746,7 @@ int vp_infer_submit(vp_handle c, const void* crops, int32_t fmt, int32_t n, cons
     if (!slot_out) return fail(c, VP_ERR_INVALID, "null slot pointer");
     if (n <= 0 || n > c->maxb) return fail(c, VP_ERR_INVALID, "vp_infer_submit takes 1 .. max_batch crops per call");
     if (!c->copy_stream) HIPCHK(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+    if (!c->d2h_stream) HIPCHK(c, hipStreamCreateWithFlags(&c->d2h_stream, hipStreamNonBlocking));
     const int si = c->next_slot;
     vp_ctx::Slot& sl = c->slots[si];
     if (sl.busy) return fail(c, VP_ERR_STATE, "both slots in flight: call vp_infer_wait first");
@@ -766,10 +768,10 @@ int vp_infer_submit(vp_handle c, const void* crops, int32_t fmt, int32_t n, cons
     HIPCHK(c, hipStreamWaitEvent(c->stream, sl.h2d, 0));
     if ((rc = run_chunk(c, sl.in, fmt, n, org_wh ? sl.wh : nullptr, sl.kp))) return rc;
     HIPCHK(c, hipEventRecord(sl.done, c->stream));
-    // copy stream: D2H of the keypoints after the compute
-    HIPCHK(c, hipStreamWaitEvent(c->copy_stream, sl.done, 0));
-    HIPCHK(c, hipMemcpyAsync(out, sl.kp, (size_t)n * c->Kp * 12, hipMemcpyDeviceToHost, c->copy_stream));
-    HIPCHK(c, hipEventRecord(sl.out, c->copy_stream));
+    // download stream: D2H of the keypoints after the compute
+    HIPCHK(c, hipStreamWaitEvent(c->d2h_stream, sl.done, 0));
+    HIPCHK(c, hipMemcpyAsync(out, sl.kp, (size_t)n * c->Kp * 12, hipMemcpyDeviceToHost, c->d2h_stream));
+    HIPCHK(c, hipEventRecord(sl.out, c->d2h_stream));
     sl.busy = true;
     *slot_out = si;
     c->next_slot = si ^ 1;
@@ -1081,6 +1083,7 @@ int vp_destroy(vp_handle c) {
     for (auto& ge : c->graphs) if (ge.exec) hipGraphExecDestroy(ge.exec);
     for (void* p : c->allocs) hipFree(p);
     if (c->copy_stream) { hipStreamSynchronize(c->copy_stream); hipStreamDestroy(c->copy_stream); }
+    if (c->d2h_stream) { hipStreamSynchronize(c->d2h_stream); hipStreamDestroy(c->d2h_stream); }
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
     return VP_OK;
