@@ -720,6 +720,27 @@ int vp_infer_device_stream(vp_handle c, const void* d_crops, int32_t fmt, int32_
 int vp_infer(vp_handle c, const void* crops, int32_t fmt, int32_t n, const int32_t* org_wh, float* out) {
     int rc = check_ready(c, fmt, n, crops, out);
     if (rc) return rc;
+    if (n > c->maxb && !c->slots[0].busy && !c->slots[1].busy) {
+        // more than one chunk: through the two asynchronous slots, so that the upload of chunk i+1 and the download of chunk i-1
+        // run under the compute of chunk i (fully overlapped when the caller's buffers are pinned; pageable buffers still work,
+        // the runtime stages them synchronously)
+        int pending[2], np = 0;
+        for (int off = 0; off < n; off += c->maxb) {
+            const int nb = (n - off < c->maxb) ? n - off : c->maxb;
+            int32_t slot = -1;
+            rc = vp_infer_submit(c, (const char*)crops + (size_t)off * crop_bytes(fmt), fmt, nb, org_wh ? org_wh + 2 * (size_t)off : nullptr,
+                                 out + (size_t)off * c->Kp * 3, &slot);
+            if (rc) { for (int i = 0; i < np; ++i) vp_infer_wait(c, pending[i]); return rc; }
+            pending[np++] = slot;
+            if (np == 2) {
+                if ((rc = vp_infer_wait(c, pending[0]))) { vp_infer_wait(c, pending[1]); return rc; }
+                pending[0] = pending[1]; np = 1;
+            }
+        }
+        for (int i = 0; i < np; ++i)
+            if ((rc = vp_infer_wait(c, pending[i]))) return rc;
+        return VP_OK;
+    }
     for (int off = 0; off < n; off += c->maxb) {
         const int nb = (n - off < c->maxb) ? n - off : c->maxb;
         const char* src = (const char*)crops + (size_t)off * crop_bytes(fmt);
