@@ -352,7 +352,31 @@ __global__ __launch_bounds__(NW * 64, 1) void issue_probe_kernel(int iters, char
     if (s4[0] + fs == 12345.f) sink[threadIdx.x] = s4[1] + ((float*)smem)[threadIdx.x];
 }
 
+// the same MFMA work per round as issue_probe_kernel mode 0 in the 32x32x16 shape (8 MFMAs of 32 matrix-pipe cycles), DEP = number
+// of independent accumulators (8: no dependent pair closer than 8 MFMAs; 4 / 2: dependent issue distance 4 / 2)
+template <int NW, int DEP>
+__global__ __launch_bounds__(NW * 64, 1) void issue_probe32_kernel(int iters, float* sink) {
+    typedef __attribute__((ext_vector_type(16))) float f32x16;
+    u32x4 a = {0x3c003c00u + threadIdx.x, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u};
+    u32x4 b = {0x38003800u, 0x38003800u + threadIdx.x, 0x38003800u, 0x38003800u};
+    f32x16 acc[DEP];
+#pragma unroll
+    for (int i = 0; i < DEP; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            acc[i % DEP] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), acc[i % DEP], 0, 0, 0);
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < DEP; ++i) s += acc[i][0] + acc[i][5];
+    if (s == 12345.f) sink[threadIdx.x] = s;
+}
+
 // kind 0: MFMA 16x16x32 f16, 1: MFMA 32x32x16 f16 (returns TFLOP/s); 2: float4 copy (returns TB/s read+write);
+// 170 + (0 | 1 | 2: 8 / 4 / 2 independent accumulators) (+ 4: two waves per SIMD): the 32x32x16 probe, nanoseconds per round
 // 100 + mode (+ 32: two waves per SIMD; mode bit 4: 1 MiB = L2-resident buffers): issue probe, returns nanoseconds per round
 // 3 / 4 / 5 / 6: LDS-DMA stream from a 32 MiB / 1 GiB / 2 MiB / 256 KiB source, 2 blocks per CU (TB/s into LDS)
 hipError_t peak_bench(int kind, double* result) {
@@ -373,6 +397,23 @@ hipError_t peak_bench(int kind, double* result) {
         hipEventElapsedTime(&ms, e0, e1);
         const double flops = (double)blocks * 4 * iters * (kind == 0 ? 16.0 * 16384 : 4.0 * 32768);
         *result = flops / (ms * 1e-3) / 1e12;
+        hipFree(d);
+    } else if (kind >= 170 && kind < 178) {
+        const int dep = (kind - 170) & 3, two = (kind - 170) & 4;
+        float* d;
+        hipMalloc(&d, 4096);
+        const int iters = 8000;
+        for (int rep = 0; rep < 2; ++rep) {
+            hipEventRecord(e0, nullptr);
+#define VP_P32(NW, D) hipLaunchKernelGGL((issue_probe32_kernel<NW, D>), dim3(256), dim3(NW * 64), 0, nullptr, iters, d)
+            if (!two) { if (dep == 0) VP_P32(4, 8); else if (dep == 1) VP_P32(4, 4); else VP_P32(4, 2); }
+            else { if (dep == 0) VP_P32(8, 8); else if (dep == 1) VP_P32(8, 4); else VP_P32(8, 2); }
+#undef VP_P32
+            hipEventRecord(e1, nullptr);
+            hipDeviceSynchronize();
+        }
+        hipEventElapsedTime(&ms, e0, e1);
+        *result = (double)ms * 1e6 / iters;
         hipFree(d);
     } else if (kind >= 100 && kind < 164) {
         const int mode = (kind - 100) & 31, nw = (kind - 100) & 32 ? 8 : 4;

@@ -101,7 +101,12 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs g) {
     const int w1off = wc * 16 * C::NF1 * 128 + foff;  // W half 1
 
     f32x4 acc[C::TI][8];
-    u32x4 xs[4][2], w0[2][2], w1[C::NF1][2];
+    // fragment registers.  W: two sets that swap roles every K-tile (W0 of K-tile t <-> W1 of t, then W0 of t+1).  X: xs holds the
+    // fragments read in the phase that uses them first; PX fragments of X1 are read one phase early (xp, in P2) and PQ fragments of
+    // the NEXT K-tile's X0 in P4 (xq), so that the LDS reads of the four load intervals are as even as the registers allow
+    // (BN = 256: 6 / 6 / 6 / 6 ds_read_b128 instead of 12 / 4 / 8 / 0).
+    constexpr int PX = C::PX, PQ = C::PQ;
+    u32x4 xs[4][2], fa[2][2], fb[2][2], xp[PX > 0 ? PX : 1][2], xq[PQ > 0 ? PQ : 1][2];
 
     auto zero_acc = [&]() {
 #pragma unroll
@@ -110,101 +115,170 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs g) {
             for (int j = 0; j < 8; ++j) acc[f][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     };
 
-    // one K-tile: ring buffer B holds it; kn1 / kn2 = K-tile indices (relative to the ISSUE tile pointers) of the
-    // K-tiles one and two ahead; sw = switch the issue pointers to the next tile after P1 (the K-tile two ahead, and
-    // from then on everything issued, belongs to the next tile)
-    unsigned long long ks[4] = {0, 0, 0, 0};   // tools/gemm8_timeline.py (ablate 32): P4 wait of K-tiles 0 and 1 of a tile, begin / end
-    auto ktile = [&](auto Bc, int kn1, int kn2, bool sw, int nm0, int nn0, int stamp = -1) {
+    // one K-tile t: ring buffer B holds it; kn2 = K-tile index (relative to the ISSUE tile pointers) of the K-tile two ahead, whose
+    // four slots are restaged here, one per phase; sw = switch the issue pointers to the next tile first.
+    // MODE 1 = first K-tile of a tile (W0 and all of X0 are read here; the W0 restage moves to P2),
+    // MODE 2 = last K-tile of a tile (no read-ahead of the next K-tile: no fragment is live across the epilogue).
+    unsigned long long ks[4] = {0, 0, 0, 0};   // tools/gemm8_timeline.py (ablate 32): P3 wait of K-tiles 0 and 1 of a tile, begin / end
+#ifndef VP_G8_ABL
+#define VP_G8_ABL 0   // diagnosis builds (tools/gemm8_ablate2.py, tools/gemm8_timeline.py): 1 = no fragment reads after a tile's first K-tile,
+                      // 2 = no barriers in the main loop, 4 = no MFMAs, 16 = cycle stamps around every section of one K-tile
+#endif
+#define KBAR() do { if (!(VP_G8_ABL & 2)) bar(); } while (0)
+#if (VP_G8_ABL & 16)
+    unsigned long long sec[24];
+#pragma unroll
+    for (int i = 0; i < 24; ++i) sec[i] = 0;
+#define SEC(i) do { if (stamp == 2) sec[i] = __builtin_readcyclecounter(); } while (0)
+#else
+#define SEC(i) do { } while (0)
+#endif
+    auto ktile = [&](auto Bc, auto Mc, int kn2, bool sw, int nm0, int nn0, int stamp = -1) {
         constexpr int B = decltype(Bc)::value;
+        constexpr int MODE = decltype(Mc)::value;
         const char* sb = smem + B * C::BUF;
-        // ---------------- P1
-#pragma unroll
-        for (int p = 0; p < 2; ++p)
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) w0[p][kk] = *(const u32x4*)(sb + C::OFF_W0 + ((w0off + p * 2048) ^ (kk << 6)));
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) xs[j][kk] = *(const u32x4*)(sb + C::OFF_X0 + ((xoff + j * 2048) ^ (kk << 6)));
-        __builtin_amdgcn_sched_barrier(0);
-        issue(1, B ^ 1, kn1);
+        const char* sn = smem + (B ^ 1) * C::BUF;
+        u32x4(&w0)[2][2] = (B == 0) ? fa : fb;   // W0 of this K-tile
+        u32x4(&w1)[2][2] = (B == 0) ? fb : fa;   // W1 of this K-tile, then (P4) W0 of the next one
+        auto x0f = [&](int j, int kk) -> u32x4& { return j < 4 - PQ ? xs[j][kk] : xq[j - (4 - PQ)][kk]; };
+        auto x1f = [&](int j, int kk) -> u32x4& { return j < 4 - PX ? xs[j][kk] : xp[j - (4 - PX)][kk]; };
         if (sw) set_tile(nm0, nn0);
-        wait_lgkm<8>();   // the four W0 reads (issued first) have returned: slot W0 may be restaged in P2
-        bar();
+        SEC(0);
+        // ---------------- P1: X0 | DMA W0(t+2)
+        if constexpr (MODE == 1) {
+#pragma unroll
+            for (int p = 0; p < 2; ++p)
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) w0[p][kk] = *(const u32x4*)(sb + C::OFF_W0 + ((w0off + p * 2048) ^ (kk << 6)));
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int j = 0; j < (MODE == 1 ? 4 : 4 - PQ); ++j)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) if (MODE == 1 || !(VP_G8_ABL & 1)) x0f(j, kk) = *(const u32x4*)(sb + C::OFF_X0 + ((xoff + j * 2048) ^ (kk << 6)));
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (MODE != 1) issue(2, B, kn2);
+        wait_lgkm<0>();   // every read of this phase has returned before the barrier: its slot may be restaged one phase later
+        SEC(1);
+        KBAR();
+        SEC(2);
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
             for (int p = 0; p < 2; ++p)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[p][j] = mfma16<T>(w0[p][kk], xs[j][kk], acc[p][j]);
+                for (int j = 0; j < 4; ++j) if (!(VP_G8_ABL & 4)) acc[p][j] = mfma16<T>(w0[p][kk], x0f(j, kk), acc[p][j]);
         __builtin_amdgcn_s_setprio(0);
-        bar();
-        // ---------------- P2
+        SEC(3);
+        KBAR();
+        SEC(4);
+        // ---------------- P2: W1 + the first PX fragments of X1 | DMA X0(t+2)
 #pragma unroll
         for (int p = 0; p < C::NF1; ++p)
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk) w1[p][kk] = *(const u32x4*)(sb + C::OFF_W1 + ((w1off + p * 2048) ^ (kk << 6)));
+            for (int kk = 0; kk < 2; ++kk) if (!(VP_G8_ABL & 1)) w1[p][kk] = *(const u32x4*)(sb + C::OFF_W1 + ((w1off + p * 2048) ^ (kk << 6)));
+#pragma unroll
+        for (int j = 4 - PX; j < 4; ++j)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) if (!(VP_G8_ABL & 1)) x1f(j, kk) = *(const u32x4*)(sb + C::OFF_X1 + ((xoff + j * 2048) ^ (kk << 6)));
         __builtin_amdgcn_sched_barrier(0);
-        issue(2, B, kn2);
-        bar();
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-            for (int p = 0; p < C::NF1; ++p)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[2 + p][j] = mfma16<T>(w1[p][kk], xs[j][kk], acc[2 + p][j]);
-        __builtin_amdgcn_s_setprio(0);
-        bar();
-        // ---------------- P3
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) xs[j][kk] = *(const u32x4*)(sb + C::OFF_X1 + ((xoff + j * 2048) ^ (kk << 6)));
-        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (MODE == 1) issue(2, B, kn2);
         issue(0, B, kn2);
-        bar();
+        wait_lgkm<0>();
+        SEC(5);
+        KBAR();
+        SEC(6);
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
             for (int p = 0; p < C::NF1; ++p)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[2 + p][4 + j] = mfma16<T>(w1[p][kk], xs[j][kk], acc[2 + p][4 + j]);
+                for (int j = 0; j < 4; ++j) if (!(VP_G8_ABL & 4)) acc[2 + p][j] = mfma16<T>(w1[p][kk], x0f(j, kk), acc[2 + p][j]);
         __builtin_amdgcn_s_setprio(0);
-        bar();
-        // ---------------- P4
+        SEC(7);
+        KBAR();
+        SEC(8);
+        // ---------------- P3: the rest of X1 | DMA W1(t+2) | counted wait: K-tile t+1 complete
+#pragma unroll
+        for (int j = 0; j < 4 - PX; ++j)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) if (!(VP_G8_ABL & 1)) x1f(j, kk) = *(const u32x4*)(sb + C::OFF_X1 + ((xoff + j * 2048) ^ (kk << 6)));
+        __builtin_amdgcn_sched_barrier(0);
         issue(3, B, kn2);
         if (stamp >= 0) ks[2 * stamp] = __builtin_readcyclecounter();
-        wait_vm<C::INFLIGHT>();   // everything up to P1's DMA has landed (own share): K-tile t+1 is complete
+        wait_vm<C::INFLIGHT>();   // everything up to P4(t-1)'s DMA has landed (own share): K-tile t+1 is complete
         if (stamp >= 0) ks[2 * stamp + 1] = __builtin_readcyclecounter();
-        bar();
+        wait_lgkm<0>();
+        SEC(9);
+        KBAR();
+        SEC(10);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int p = 0; p < C::NF1; ++p)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) if (!(VP_G8_ABL & 4)) acc[2 + p][4 + j] = mfma16<T>(w1[p][kk], x1f(j, kk), acc[2 + p][4 + j]);
+        __builtin_amdgcn_s_setprio(0);
+        SEC(11);
+        KBAR();
+        SEC(12);
+        // ---------------- P4: W0 and the last PQ fragments of X0 of K-tile t+1 (from the other buffer) | DMA X1(t+2)
+        if constexpr (MODE != 2) {
+#pragma unroll
+            for (int p = 0; p < 2; ++p)
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) if (!(VP_G8_ABL & 1)) w1[p][kk] = *(const u32x4*)(sn + C::OFF_W0 + ((w0off + p * 2048) ^ (kk << 6)));
+#pragma unroll
+            for (int j = 4 - PQ; j < 4; ++j)
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) if (!(VP_G8_ABL & 1)) x0f(j, kk) = *(const u32x4*)(sn + C::OFF_X0 + ((xoff + j * 2048) ^ (kk << 6)));
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        issue(1, B, kn2);
+        wait_lgkm<0>();
+        SEC(13);
+        KBAR();
+        SEC(14);
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
             for (int p = 0; p < 2; ++p)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[p][4 + j] = mfma16<T>(w0[p][kk], xs[j][kk], acc[p][4 + j]);
+                for (int j = 0; j < 4; ++j) if (!(VP_G8_ABL & 4)) acc[p][4 + j] = mfma16<T>(w0[p][kk], x1f(j, kk), acc[p][4 + j]);
         __builtin_amdgcn_s_setprio(0);
+        SEC(15);
+        KBAR();
+        SEC(16);
+    };
+#undef SEC
+#undef KBAR
+    using M0 = std::integral_constant<int, 0>;
+    using M1 = std::integral_constant<int, 1>;
+    using M2 = std::integral_constant<int, 2>;
+    using B0 = std::integral_constant<int, 0>;
+    using B1 = std::integral_constant<int, 1>;
+    // (re)start of the ring on the issue tile: K-tiles 0 and 1 completely issued, K-tile 0 landed and visible
+    auto ring_start = [&]() {
+        issue(2, 0, 0, true); issue(0, 0, 0, true); issue(3, 0, 0, true); issue(1, 0, 0, true);
+        issue(2, 1, 1, true); issue(0, 1, 1, true); issue(3, 1, 1, true); issue(1, 1, 1, true);
+        wait_vm<C::INFLIGHT + 2>();   // the eight DMA pieces of K-tile 1 stay in flight
         bar();
+        if (wr) bar();   // stagger: waves 4-7 run one barrier behind waves 0-3
     };
 
     if (g.stagger > 0) {   // XCD x starts x * stagger sleep quanta late: the XCDs' store bursts no longer coincide
         const int n = (blockIdx.x & 7) * g.stagger;
         for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(127);
     }
-    // ---- prologue of the first tile: K-tile 0 complete, W0 / X0 / W1 of K-tile 1 in flight ----
+    // ---- prologue of the first tile: K-tile 0 complete, K-tile 1 in flight ----
     int t = tw.j0, m0, n0;
     tw.origin(t, g.reverse, C::BM, C::BN, m0, n0);
     set_tile(m0, n0);
-    issue(2, 0, 0, true); issue(0, 0, 0, true); issue(3, 0, 0, true); issue(1, 0, 0, true);
-    issue(2, 1, 1, true); issue(0, 1, 1, true); issue(3, 1, 1, true);
-    wait_vm<C::INFLIGHT>();
-    bar();
-    if (wr) bar();   // stagger: waves 4-7 run one barrier behind waves 0-3
+    ring_start();
 
     for (;;) {
         zero_acc();
@@ -214,13 +288,15 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs g) {
         const bool tl = (g.ablate & 32) != 0;
         unsigned long long ts0 = 0, ts1 = 0;
         if (tl) ts0 = __builtin_readcyclecounter();
-        for (int kt = 0; kt < nk - 2; kt += 2) {
-            ktile(std::integral_constant<int, 0>{}, kt + 1, kt + 2, false, 0, 0, (tl && kt == 0) ? 0 : -1);
-            ktile(std::integral_constant<int, 1>{}, kt + 2, kt + 3, false, 0, 0, (tl && kt == 0) ? 1 : -1);
+        ktile(B0{}, M1{}, 2, false, 0, 0, tl ? 0 : -1);
+        ktile(B1{}, M0{}, 3, false, 0, 0, tl ? 1 : -1);
+        for (int kt = 2; kt < nk - 2; kt += 2) {
+            ktile(B0{}, M0{}, kt + 2, false, 0, 0, (tl && kt == 4) ? 2 : -1);
+            ktile(B1{}, M0{}, kt + 3, false, 0, 0);
         }
-        // last two K-tiles: K-tile nk-2 still issues X1 of K-tile nk-1 from this tile, everything after it is the next tile's
-        ktile(std::integral_constant<int, 0>{}, nk - 1, 0, true, nm0, nn0);
-        ktile(std::integral_constant<int, 1>{}, 0, 1, false, 0, 0);
+        // last two K-tiles: everything they restage belongs to the next tile
+        ktile(B0{}, M0{}, 0, true, nm0, nn0);
+        ktile(B1{}, M2{}, 1, false, 0, 0);
         if (tl) ts1 = __builtin_readcyclecounter();
 
         // ---------------- epilogue of tile (m0, n0) ----------------
@@ -295,6 +371,13 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs g) {
                     unsigned long long* sp = (unsigned long long*)g.stats_out + (((size_t)blockIdx.x * 2 + wr) * 16 + ti) * 8;
                     sp[0] = ts0; sp[1] = ts1; sp[2] = __builtin_readcyclecounter();
                     sp[3] = ks[0]; sp[4] = ks[1]; sp[5] = ks[2]; sp[6] = ks[3];
+#if (VP_G8_ABL & 16)
+                    if (ti == 1) {
+                        unsigned long long* sq = (unsigned long long*)g.stats_out + (((size_t)blockIdx.x * 2 + wr) * 16 + 8) * 8;
+#pragma unroll
+                        for (int i = 0; i < 24; ++i) sq[i] = sec[i];
+                    }
+#endif
                 }
             }
         } else {
@@ -387,13 +470,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs g) {
                     *(float2*)(g.stats_out + ((size_t)(m0 + trow) * (g.N / 64) + ((n0 >> 6) + gi)) * 2) = *(const float2*)(statbuf + i * 2);
             }
             __syncthreads();
-            if (has_next) {   // restart the ring on the next tile (issue pointers already point at it)
-                issue(2, 0, 0, true); issue(0, 0, 0, true); issue(3, 0, 0, true); issue(1, 0, 0, true);
-                issue(2, 1, 1, true); issue(0, 1, 1, true); issue(3, 1, 1, true);
-                wait_vm<C::INFLIGHT>();
-                bar();
-                if (wr) bar();
-            }
+            if (has_next) ring_start();   // restart the ring on the next tile (the issue pointers already point at it)
         }
         if (!has_next) break;
         t += tw.nloc;

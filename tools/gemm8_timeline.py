@@ -41,3 +41,13 @@ for name, epi, N, flags in (('qkv', 0, 3 * D, 16), ('fc1', 1, 4 * D, 16 | 2)):
     print(f'  gap epilogue end -> next loop begin {np.median(gap, 0).astype(int).tolist()}')
     tot = t0[:, 0, ntile - 1, 2].max() - start
     print(f'  launch span {tot} cycles; epilogue-begin spread per tile (max - min over workgroups): {(t0[:, 0, :, 1].max(0) - t0[:, 0, :, 1].min(0)).tolist()}')
+    sec = s[:, :, 8:11, :].reshape(256, 2, 24)
+    if (sec[:, 0, 1] > 0).any():   # diagnosis build (-DVP_G8_ABL=16): section stamps of K-tile 4 of each workgroup's second tile
+        names = []
+        for ph in range(1, 5):
+            names += [f'P{ph} load->lgkm', f'P{ph} bar', f'P{ph} mfma issue', f'P{ph} bar2']
+        for grp in (0, 1):
+            d = np.diff(sec[:, grp, :17], axis=1)
+            ok = (sec[:, grp, 1] > 0)
+            med = np.median(d[ok], 0).astype(int)
+            print(f'  group {grp} sections of one K-tile (median cycles): ' + ', '.join(f'{n}={v}' for n, v in zip(names, med)) + f'  total {int(med.sum())}')

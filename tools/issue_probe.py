@@ -16,3 +16,9 @@ for two in (0, 32):
         rc = lib.vp_dbg_peak(0, 100 + mode + two, C.byref(r))
         base = base or r.value
         print(f'{2 if two else 1} wave(s)/SIMD  {name:32s}: {r.value:8.1f} ns/round  (+{r.value - base:6.1f})  rc={rc}', flush=True)
+
+for two in (0, 4):
+    for dep, name in ((0, '8 accumulators'), (1, '4 accumulators'), (2, '2 accumulators')):
+        r = C.c_double()
+        rc = lib.vp_dbg_peak(0, 170 + dep + two, C.byref(r))
+        print(f'{2 if two else 1} wave(s)/SIMD  32x32x16 MFMA only, {name:20s}: {r.value:8.1f} ns/round (8 MFMAs = the flops of 16 16x16x32)  rc={rc}', flush=True)
