@@ -8,20 +8,24 @@
 //    Every wave owns a 128(m) x BN/4(n) output block made of 64 rows from EACH X half and BN/8 (BN = 256) rows from each W
 //    half, so its accumulators split into four quadrants q(hm, hn) = X-half hm x W-half hn, and a quadrant needs exactly
 //    one X slot and one W slot.
-//  * 4 phases per K-tile, 8 per loop iteration (two K-tiles, compile-time buffer index):
-//        P1: read W0 + X0 fragments | DMA X1(t+1) | barrier | MFMA q00 | barrier
-//        P2: read W1 fragments      | DMA W0(t+2) | barrier | MFMA q01 | barrier
-//        P3: read X1 fragments      | DMA X0(t+2) | barrier | MFMA q11 | barrier
-//        P4: (W0 kept in registers) | DMA W1(t+2) | vmcnt | barrier | MFMA q10 | barrier
-//    One slot is restaged per phase (global_load_lds, 16 B per lane); the only vmcnt wait of a K-tile sits in P4 and is
-//    COUNTED (the three youngest slots stay in flight across it), so HBM/L2 latency is covered by 3-6 phases of MFMAs.
+//  * 4 phases per K-tile, 8 per loop iteration (two K-tiles, compile-time buffer index and fragment-set roles):
+//        P1: read X0 fragments (8 ds_read_b128)            | DMA W0(t+2) | lgkmcnt(0) | barrier | MFMA q00 | barrier
+//        P2: read W1 fragments (4)                         | DMA X0(t+2) | lgkmcnt(0) | barrier | MFMA q01 | barrier
+//        P3: read X1 fragments (8)                         | DMA W1(t+2) | vmcnt | lgkmcnt(0) | barrier | MFMA q11 | barrier
+//        P4: read W0 fragments of K-tile t+1 (4, other buffer, into the set W1 just left) | DMA X1(t+2) | lgkmcnt(0) | barrier | MFMA q10 | barrier
+//    One slot is restaged per phase (global_load_lds, 16 B per lane); the only vmcnt wait of a K-tile sits in P3 and is
+//    COUNTED (the three youngest slots stay in flight across it), so HBM/L2 latency is covered by 3 phases of MFMAs.
+//    The first K-tile of a tile reads its W0 in P1 (nothing is live across the epilogue) and restages W0 in P2 instead.
 //  * two wave groups (waves 0-3 / 4-7 = the two waves of every SIMD) run the same stream ONE BARRIER APART: while
 //    one wave of a SIMD streams its 16 MFMAs, its SIMD partner reads fragments and issues the DMA of its phase.
 //  * ordering rules the schedule is built on (MI355X_MICROARCH.md, "Two waves per SIMD", item 7):
-//      RAW: a slot is read one phase AFTER the phase whose vmcnt retired it (P4(t) retires K-tile t+1, read from P1(t+1));
-//      WAR: a slot is restaged >= 2 phases after its last ds_read (X0: P1 -> P3, W1: P2 -> P4, X1: P3 -> P1 of the next
-//           K-tile), or 1 phase after when those reads were retired by an lgkmcnt BEFORE the reading phase's first
-//           barrier (W0: read first in P1, `s_waitcnt lgkmcnt(8)` before the barrier, restaged in P2).
+//      RAW: a slot is read one phase AFTER the phase whose vmcnt retired it (P3(t) retires K-tile t+1, first read in P4(t));
+//      WAR: every LOAD section ends with lgkmcnt(0) BEFORE the phase's first barrier, so a slot may be restaged in the
+//           next phase: X0 P1 -> P2, W1 P2 -> P3, X1 P3 -> P4, W0(t+1) P4(t) -> P1(t+1).
+//    (Round 2 history: the first version read W0 + X0 in P1 and nothing in P4 (12 / 4 / 8 / 0 reads) with the wait in P4; this
+//    one measures 1.2 % faster end to end on the same box.  profiles/gemm8_sections_r2.txt has the section timings and the
+//    variants that were measured and not shipped: one barrier per phase, W reads inside the MFMA sections, 6/6/6/6 reads,
+//    32x32x16 MFMAs.)
 //  * the LDS image of a slot is lane-linear (global_load_lds writes wave base + lane * 16): the XOR swizzle of the
 //    16-byte k-slots is applied to the per-lane SOURCE address and again on the ds_read_b128 fragment reads.
 //  * persistent workgroups: the ring runs on across tile boundaries (the next tile's first two K-tiles stream in during
