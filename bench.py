@@ -84,7 +84,7 @@ FAMILIES = {
 
 def kernel_label(fam, T, B, shp):
     """Name of the kernel a family runs on at this batch size.  The 8-phase kernel takes a GEMM when its row count is a multiple
-    of 256 and the launch has >= 512 output tiles (vitpose_api.hip: gemm()); smaller launches run gemm_kernel's tile table."""
+    of 256 and the launch has >= 448 output tiles (vitpose_api.hip: gemm()); smaller launches run gemm_kernel's tile table."""
     pre, what = FAMILIES[fam]
     if pre.startswith('gemm8'):
         M = B * 192
@@ -93,7 +93,7 @@ def kernel_label(fam, T, B, shp):
         ncols = {'gemm_fc1': 4 * D // 256, 'gemm_qkv': 3 * D // 256, 'gemm_fc2': D // bn2}[fam]
         if fam == 'gemm_fc2' and bn2 == 256:
             what = what.replace('256x192', '256x256')
-        if M % 256 or (M // 256) * ncols < 512 or (fam == 'gemm_fc2' and D % bn2):
+        if M % 256 or (M // 256) * ncols < 448 or (fam == 'gemm_fc2' and D % bn2):
             return f'gemm_kernel<{T}, ...> tile table (shape or launch size outside the set of the 8-phase kernel): ' + what.split(',')[0]
     return pre.format(T=T) + ' ...>: ' + what
 

@@ -384,7 +384,7 @@ int gemm(vp_ctx* c, int fam, int epi, const uint16_t* A, const uint16_t* W, cons
         if (ln->tiles_out) *ln->tiles_out = N / 64;   // partial statistics are written per 64 columns, whatever the tile
     }
     // large batches: the 8-phase persistent kernel (gemm8.hip), one 512-thread workgroup per CU on 256 x 256 (wide GEMMs) or
-    // 256 x 192 (N = D: 768 = 4 x 192, three full rounds of 256 workgroups at batch 256) tiles, when every CU gets >= 2 tiles
+    // 256 x 192 (N = D: 768 = 4 x 192, three full rounds of 256 workgroups at batch 256) tiles, when every CU gets >= 1.75 tiles
     // (attn.proj, K = N = D, is HBM-bound and stays on the 192 x 128 tile with two workgroups per CU: measured 105 vs 112 us;
     // bit 3 of VP_GEMM8 moves it too)
     const bool is_proj = epi == vp::EPI_BIAS_RESID_LN && K <= N;
@@ -396,7 +396,8 @@ int gemm(vp_ctx* c, int fam, int epi, const uint16_t* A, const uint16_t* W, cons
         int bn = 0;
         if (wide) bn = (N % 256 == 0) ? 256 : (N % 192 == 0 ? 192 : 0);
         else bn = (N % 192 == 0 && (long)(M / 256) * (N / 192) % 256 == 0) ? 192 : (N % 256 == 0 ? 256 : (N % 192 == 0 ? 192 : 0));
-        if (bn && (long)(M / 256) * (N / bn) >= 512 && vp::gemm8_supported(epi, g, bn)) {
+        static const long min_tiles = [] { const char* e = getenv("VP_G8_MIN_TILES"); return e ? atol(e) : 448L; }();   // >= 1.75 tiles per CU (ViTPose-H fc2 at batch 128: 480 tiles, 329 -> 279 us)
+        if (bn && (long)(M / 256) * (N / bn) >= min_tiles && vp::gemm8_supported(epi, g, bn)) {
             g.variant = bn == 256 ? (wide && c->g8_deferred ? 19 : 16) : 17;
             g.group_m = fam == VP_PROF_GEMM_QKV ? 4 : fam == VP_PROF_GEMM_FC2 ? 2 : 8;   // measured sweep 0 / 2 / 4 / 8 / 16 / 32 (spread 2-3 %)
             g.persist = 0;
