@@ -87,14 +87,18 @@ def kernel_label(fam, T, B, shp):
     of 256 and the launch has >= 448 output tiles (vitpose_api.hip: gemm()); smaller launches run gemm_kernel's tile table."""
     pre, what = FAMILIES[fam]
     if pre.startswith('gemm8'):
-        M = B * 192
-        D = shp.embed_dim
-        bn2 = 192 if D % 192 == 0 else 256          # residual GEMMs: 256 x 192 tiles when N = D divides, else 256 x 256
-        ncols = {'gemm_fc1': 4 * D // 256, 'gemm_qkv': 3 * D // 256, 'gemm_fc2': D // bn2}[fam]
-        if fam == 'gemm_fc2' and bn2 == 256:
-            what = what.replace('256x192', '256x256')
-        if M % 256 or (M // 256) * ncols < 448 or (fam == 'gemm_fc2' and D % bn2):
+        M, D = B * 192, shp.embed_dim
+        N = {'gemm_fc1': 4 * D, 'gemm_qkv': 3 * D, 'gemm_fc2': D}[fam]
+        best = None                                   # (fill of the last round of 256 workgroups, tiles, tile width): as vitpose_api.hip gemm()
+        for bn in ((256, 192) if fam == 'gemm_fc2' else (256,)):
+            if N % bn == 0 and M % 256 == 0:
+                t = (M // 256) * (N // bn)
+                f = t / (-(-t // 256) * 256)
+                if best is None or f > best[0] + 1e-9:
+                    best = (f, t, bn)
+        if best is None or not (best[1] >= 448 or (best[0] >= 0.8 and best[1] >= 192)):
             return f'gemm_kernel<{T}, ...> tile table (shape or launch size outside the set of the 8-phase kernel): ' + what.split(',')[0]
+        what = what.replace('256x192', f'256x{best[2]}')
     return pre.format(T=T) + ' ...>: ' + what
 
 

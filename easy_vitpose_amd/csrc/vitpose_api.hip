@@ -393,11 +393,21 @@ int gemm(vp_ctx* c, int fam, int epi, const uint16_t* A, const uint16_t* W, cons
     if (c->gemm_variant[fam] < 0 && (c->gemm8_mask & g8bit) &&
         (epi == vp::EPI_BIAS || epi == vp::EPI_BIAS_GELU || epi == vp::EPI_BIAS_RESID_LN) && M % 256 == 0) {
         const bool wide = epi != vp::EPI_BIAS_RESID_LN;
+        // tile width: the candidate (256; for the residual GEMMs also 192) whose tile count fills the rounds of 256 persistent
+        // workgroups best; the kernel is used from 1.75 tiles per CU, or for a smaller launch when its last round is >= 80 % full
+        // (measured at batch 32 - 128: ViTPose-B qkv at 216 / 432 tiles -15 % / -5 %, fc2 at 216 tiles -23 %, but fc1 / fc2 at
+        // 288 tiles = 56 % full +20 %; ViTPose-H fc2 at batch 128, 480 tiles: 329 -> 279 us)
+        static const long min_tiles = [] { const char* e = getenv("VP_G8_MIN_TILES"); return e ? atol(e) : 448L; }();
         int bn = 0;
-        if (wide) bn = (N % 256 == 0) ? 256 : (N % 192 == 0 ? 192 : 0);
-        else bn = (N % 192 == 0 && (long)(M / 256) * (N / 192) % 256 == 0) ? 192 : (N % 256 == 0 ? 256 : (N % 192 == 0 ? 192 : 0));
-        static const long min_tiles = [] { const char* e = getenv("VP_G8_MIN_TILES"); return e ? atol(e) : 448L; }();   // >= 1.75 tiles per CU (ViTPose-H fc2 at batch 128: 480 tiles, 329 -> 279 us)
-        if (bn && (long)(M / 256) * (N / bn) >= min_tiles && vp::gemm8_supported(epi, g, bn)) {
+        long tiles = 0;
+        double fill = 0.0;
+        for (int cand : {256, 192}) {
+            if (N % cand || (wide && cand != 256)) continue;
+            const long t = (long)(M / 256) * (N / cand);
+            const double f = (double)t / (double)((t + 255) / 256 * 256);
+            if (f > fill + 1e-9) { bn = cand; tiles = t; fill = f; }
+        }
+        if (bn && (tiles >= min_tiles || (fill >= 0.8 && tiles >= 192)) && vp::gemm8_supported(epi, g, bn)) {
             g.variant = bn == 256 ? (wide && c->g8_deferred ? 19 : 16) : 17;
             g.group_m = fam == VP_PROF_GEMM_QKV ? 4 : fam == VP_PROF_GEMM_FC2 ? 2 : 8;   // measured sweep 0 / 2 / 4 / 8 / 16 / 32 (spread 2-3 %)
             g.persist = 0;
@@ -606,7 +616,7 @@ int vp_create(vp_handle* out, const vp_config* cfg) {
     if (const char* f = getenv("VP_PERSIST")) c->persist_gemm = atoi(f) != 0;
     if (const char* f = getenv("VP_GEMM8")) c->gemm8_mask = atoi(f);
     if (const char* f = getenv("VP_G8_STAGGER")) c->g8_stagger = atoi(f);
-    if (const char* f = getenv("VP_GRAPH")) c->graph_max_n = atoi(f) != 0 ? 16 : 0;
+    if (const char* f = getenv("VP_GRAPH")) c->graph_max_n = atoi(f) == 1 ? 16 : atoi(f);   // 0 = off, 1 = default, n > 1: capture chunks of up to n crops
     if (const char* f = getenv("VP_FUSE_HEAD")) c->fuse_head = atoi(f) != 0;
     if (const char* f = getenv("VP_FOLD_STATS")) c->graph_max_n_stats = atoi(f) != 0 ? 16 : 0;
     if (const char* f = getenv("VP_G8_DEFERRED")) c->g8_deferred = atoi(f) != 0;
