@@ -105,12 +105,8 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs g) {
     const int w1off = wc * 16 * C::NF1 * 128 + foff;  // W half 1
 
     f32x4 acc[C::TI][8];
-    // fragment registers.  W: two sets that swap roles every K-tile (W0 of K-tile t <-> W1 of t, then W0 of t+1).  X: xs holds the
-    // fragments read in the phase that uses them first; PX fragments of X1 are read one phase early (xp, in P2) and PQ fragments of
-    // the NEXT K-tile's X0 in P4 (xq), so that the LDS reads of the four load intervals are as even as the registers allow
-    // (BN = 256: 6 / 6 / 6 / 6 ds_read_b128 instead of 12 / 4 / 8 / 0).
-    constexpr int PX = C::PX, PQ = C::PQ;
-    u32x4 xs[4][2], fa[2][2], fb[2][2], xp[PX > 0 ? PX : 1][2], xq[PQ > 0 ? PQ : 1][2];
+    // fragment registers.  W: two sets that swap roles every K-tile (W0 of K-tile t <-> W1 of t, then W0 of t+1)
+    u32x4 xs[4][2], fa[2][2], fb[2][2];
 
     auto zero_acc = [&]() {
 #pragma unroll
@@ -144,8 +140,6 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs g) {
         const char* sn = smem + (B ^ 1) * C::BUF;
         u32x4(&w0)[2][2] = (B == 0) ? fa : fb;   // W0 of this K-tile
         u32x4(&w1)[2][2] = (B == 0) ? fb : fa;   // W1 of this K-tile, then (P4) W0 of the next one
-        auto x0f = [&](int j, int kk) -> u32x4& { return j < 4 - PQ ? xs[j][kk] : xq[j - (4 - PQ)][kk]; };
-        auto x1f = [&](int j, int kk) -> u32x4& { return j < 4 - PX ? xs[j][kk] : xp[j - (4 - PX)][kk]; };
         if (sw) set_tile(nm0, nn0);
         SEC(0);
         // ---------------- P1: X0 | DMA W0(t+2)
@@ -157,9 +151,9 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs g) {
             __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
-        for (int j = 0; j < (MODE == 1 ? 4 : 4 - PQ); ++j)
+        for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk) if (MODE == 1 || !(VP_G8_ABL & 1)) x0f(j, kk) = *(const u32x4*)(sb + C::OFF_X0 + ((xoff + j * 2048) ^ (kk << 6)));
+            for (int kk = 0; kk < 2; ++kk) if (MODE == 1 || !(VP_G8_ABL & 1)) xs[j][kk] = *(const u32x4*)(sb + C::OFF_X0 + ((xoff + j * 2048) ^ (kk << 6)));
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (MODE != 1) issue(2, B, kn2);
         wait_lgkm<0>();   // every read of this phase has returned before the barrier: its slot may be restaged one phase later
@@ -172,20 +166,16 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs g) {
 #pragma unroll
             for (int p = 0; p < 2; ++p)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) if (!(VP_G8_ABL & 4)) acc[p][j] = mfma16<T>(w0[p][kk], x0f(j, kk), acc[p][j]);
+                for (int j = 0; j < 4; ++j) if (!(VP_G8_ABL & 4)) acc[p][j] = mfma16<T>(w0[p][kk], xs[j][kk], acc[p][j]);
         __builtin_amdgcn_s_setprio(0);
         SEC(3);
         KBAR();
         SEC(4);
-        // ---------------- P2: W1 + the first PX fragments of X1 | DMA X0(t+2)
+        // ---------------- P2: W1 | DMA X0(t+2)
 #pragma unroll
         for (int p = 0; p < C::NF1; ++p)
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) if (!(VP_G8_ABL & 1)) w1[p][kk] = *(const u32x4*)(sb + C::OFF_W1 + ((w1off + p * 2048) ^ (kk << 6)));
-#pragma unroll
-        for (int j = 4 - PX; j < 4; ++j)
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) if (!(VP_G8_ABL & 1)) x1f(j, kk) = *(const u32x4*)(sb + C::OFF_X1 + ((xoff + j * 2048) ^ (kk << 6)));
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (MODE == 1) issue(2, B, kn2);
         issue(0, B, kn2);
@@ -199,16 +189,16 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs g) {
 #pragma unroll
             for (int p = 0; p < C::NF1; ++p)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) if (!(VP_G8_ABL & 4)) acc[2 + p][j] = mfma16<T>(w1[p][kk], x0f(j, kk), acc[2 + p][j]);
+                for (int j = 0; j < 4; ++j) if (!(VP_G8_ABL & 4)) acc[2 + p][j] = mfma16<T>(w1[p][kk], xs[j][kk], acc[2 + p][j]);
         __builtin_amdgcn_s_setprio(0);
         SEC(7);
         KBAR();
         SEC(8);
-        // ---------------- P3: the rest of X1 | DMA W1(t+2) | counted wait: K-tile t+1 complete
+        // ---------------- P3: X1 | DMA W1(t+2) | counted wait: K-tile t+1 complete
 #pragma unroll
-        for (int j = 0; j < 4 - PX; ++j)
+        for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk) if (!(VP_G8_ABL & 1)) x1f(j, kk) = *(const u32x4*)(sb + C::OFF_X1 + ((xoff + j * 2048) ^ (kk << 6)));
+            for (int kk = 0; kk < 2; ++kk) if (!(VP_G8_ABL & 1)) xs[j][kk] = *(const u32x4*)(sb + C::OFF_X1 + ((xoff + j * 2048) ^ (kk << 6)));
         __builtin_amdgcn_sched_barrier(0);
         issue(3, B, kn2);
         if (stamp >= 0) ks[2 * stamp] = __builtin_readcyclecounter();
@@ -224,21 +214,17 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs g) {
 #pragma unroll
             for (int p = 0; p < C::NF1; ++p)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) if (!(VP_G8_ABL & 4)) acc[2 + p][4 + j] = mfma16<T>(w1[p][kk], x1f(j, kk), acc[2 + p][4 + j]);
+                for (int j = 0; j < 4; ++j) if (!(VP_G8_ABL & 4)) acc[2 + p][4 + j] = mfma16<T>(w1[p][kk], xs[j][kk], acc[2 + p][4 + j]);
         __builtin_amdgcn_s_setprio(0);
         SEC(11);
         KBAR();
         SEC(12);
-        // ---------------- P4: W0 and the last PQ fragments of X0 of K-tile t+1 (from the other buffer) | DMA X1(t+2)
+        // ---------------- P4: W0 of K-tile t+1 (from the other buffer, into the fragment set W1 just left) | DMA X1(t+2)
         if constexpr (MODE != 2) {
 #pragma unroll
             for (int p = 0; p < 2; ++p)
 #pragma unroll
                 for (int kk = 0; kk < 2; ++kk) if (!(VP_G8_ABL & 1)) w1[p][kk] = *(const u32x4*)(sn + C::OFF_W0 + ((w0off + p * 2048) ^ (kk << 6)));
-#pragma unroll
-            for (int j = 4 - PQ; j < 4; ++j)
-#pragma unroll
-                for (int kk = 0; kk < 2; ++kk) if (!(VP_G8_ABL & 1)) x0f(j, kk) = *(const u32x4*)(sn + C::OFF_X0 + ((xoff + j * 2048) ^ (kk << 6)));
             __builtin_amdgcn_sched_barrier(0);
         }
         issue(1, B, kn2);
@@ -252,7 +238,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs g) {
 #pragma unroll
             for (int p = 0; p < 2; ++p)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) if (!(VP_G8_ABL & 4)) acc[p][4 + j] = mfma16<T>(w0[p][kk], x1f(j, kk), acc[p][4 + j]);
+                for (int j = 0; j < 4; ++j) if (!(VP_G8_ABL & 4)) acc[p][4 + j] = mfma16<T>(w0[p][kk], xs[j][kk], acc[p][4 + j]);
         __builtin_amdgcn_s_setprio(0);
         SEC(15);
         KBAR();

@@ -9,10 +9,6 @@
 namespace vp {
 namespace {
 
-#ifndef VP_G8_PX
-#define VP_G8_PX(bn) 0
-#define VP_G8_PQ(bn) 0
-#endif
 template <int BN_> struct G8 {
     static constexpr int BM = 256, BN = BN_, NT = 512;
     static constexpr int WH1 = BN - 128;            // rows of W half 1 (128 or 64)
@@ -24,8 +20,6 @@ template <int BN_> struct G8 {
     static constexpr int RING = 2 * BUF;
     static constexpr int NW1 = WH1 / 64;            // DMA instructions per wave for W half 1
     static constexpr int INFLIGHT = 4 + NW1;        // DMAs of the three youngest slots (W0, X0, W1) at the counted wait
-    // read-ahead of X fragments (gemm8.hip): PX fragments of X1 in P2, PQ fragments of the next K-tile's X0 in P4
-    static constexpr int PX = VP_G8_PX(BN_), PQ = VP_G8_PQ(BN_);
     static_assert(BN == 256 || BN == 192, "BN");
 };
 
