@@ -112,6 +112,26 @@ def test_fused_head_is_bit_identical(monkeypatch, variant, dataset, dtype, n):
     assert np.isfinite(hm).all() and float(np.abs(hm).max()) > 0
 
 
+@pytest.mark.parametrize('n', [36, 96])
+def test_mid_batch_gemm8_selection_is_bit_identical(monkeypatch, n):
+    """Between ~32 and ~128 crops the 8-phase kernel takes a GEMM when its tiles fill the last round of 256 persistent workgroups
+    (vitpose_api.hip gemm()): 36 crops -> qkv on 243 tiles over 240 workgroups (uneven XCD shares, some workgroups take two tiles),
+    96 crops -> fc2 on 216 tiles of 256 x 256 with the residual epilogue.  Same arithmetic order as the 2-phase kernels: the whole
+    path must not change by a bit against VP_GEMM8=0."""
+    shp, sd, _ = weights('b', 'coco')
+    crops = synthetic_crops(n, 41, 'blobs')
+    monkeypatch.setenv('VP_GEMM8', '0')
+    eng = VitPoseHip(shp, sd, dtype='fp16', max_batch=n)
+    ref_kp, ref_tok = eng.infer(crops), eng.tokens(crops)
+    eng.close()
+    monkeypatch.delenv('VP_GEMM8')
+    eng = VitPoseHip(shp, sd, dtype='fp16', max_batch=n)
+    kp, tok = eng.infer(crops), eng.tokens(crops)
+    eng.close()
+    assert np.array_equal(tok, ref_tok)
+    assert np.array_equal(kp, ref_kp)
+
+
 def test_group_matches_single_handle():
     """vp_group_* with every visible device (1 on the test box): sharded result == unsharded result, bit for bit; the
     device-side all-gather leaves all keypoints on every member."""
