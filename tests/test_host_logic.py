@@ -152,6 +152,25 @@ def test_bad_config_is_rejected_before_touching_a_device():
     assert lib.vp_create(None, None) == capi.VP_ERR_INVALID
 
 
+def test_null_handles_and_empty_groups_are_rejected_without_a_device():
+    """Every entry point validates its handle / pointers before it touches HIP: VP_ERR_INVALID, never a crash."""
+    lib = capi.load_library()
+    slot = C.c_int32(-1)
+    buf = np.zeros(16, np.float32)
+    assert lib.vp_infer(None, buf.ctypes.data, 0, 1, None, buf.ctypes.data) == capi.VP_ERR_INVALID
+    assert lib.vp_infer_submit(None, buf.ctypes.data, 0, 1, None, buf.ctypes.data, C.byref(slot)) == capi.VP_ERR_INVALID
+    assert lib.vp_infer_wait(None, 0) == capi.VP_ERR_INVALID
+    assert lib.vp_group_size(None) == 0
+    g = C.c_void_p()
+    cfg = capi.vp_config(384, 12, 12, 17, 0, 0, 2)
+    ids = (C.c_int32 * 1)(0)
+    assert lib.vp_group_create(C.byref(g), C.byref(cfg), ids, 0) == capi.VP_ERR_INVALID
+    assert lib.vp_group_create(None, C.byref(cfg), ids, 1) == capi.VP_ERR_INVALID
+    assert lib.vp_group_infer(None, buf.ctypes.data, 0, 1, None, buf.ctypes.data) == capi.VP_ERR_INVALID
+    lib.vp_group_destroy(None)      # a no-op, like vp_destroy(NULL)
+    lib.vp_destroy(None)
+
+
 def test_no_cpu_fallback_fails_loudly():
     import torch
     if torch.cuda.is_available():
