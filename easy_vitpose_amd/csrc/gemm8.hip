@@ -260,9 +260,11 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs g) {
         if (wr) bar();   // stagger: waves 4-7 run one barrier behind waves 0-3
     };
 
-    if (g.stagger > 0) {   // XCD x starts x * stagger sleep quanta late: the XCDs' store bursts no longer coincide
-        const int n = (blockIdx.x & 7) * g.stagger;
-        for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(127);
+    if (g.stagger > 0) {   // experiment (VP_G8_STAGGER): XCD x -- or, from 100 on, workgroup j of every XCD -- starts n * 1024 cycles late so
+                           // that the epilogues no longer coincide.  Measured at every step: the launch gets slower by exactly the delay
+                           // (the epilogue's cost is per CU, not a shared-bandwidth burst: profiles/gemm8_sections_r2.txt)
+        const int n = (g.stagger >= 100) ? (blockIdx.x >> 3) * (g.stagger - 100) : (blockIdx.x & 7) * g.stagger;   // >= 100: per workgroup inside its XCD
+        for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(16);
     }
     // ---- prologue of the first tile: K-tile 0 complete, K-tile 1 in flight ----
     int t = tw.j0, m0, n0;
@@ -391,13 +393,15 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs g) {
             f32x4 bias4[C::TI];
 #pragma unroll
             for (int f = 0; f < C::TI; ++f) bias4[f] = *(const f32x4*)(g.bias + n0 + nl + f * 4);
-            wait_vm<0>();
-            if (!wr) bar();     // undo the stagger: both groups meet here
-            __syncthreads();    // every wave is done with the ring
+            unsigned long long rs[6] = {ts0, ts1, 0, 0, 0, 0};   // tools/gemm8_timeline.py --resid: drain, passes, statistics, restart
             // staged row lr of pass p  <->  tile row (p / (4/JPP)) 128 + (lr / (16 JPP)) 64 + ((p % (4/JPP)) JPP + (lr / 16) % JPP) 16 + lr % 16
             auto tile_row = [&](int p, int lr) {
                 return (p / (4 / JPP)) * 128 + (lr / (16 * JPP)) * 64 + ((p % (4 / JPP)) * JPP + (lr / 16) % JPP) * 16 + (lr & 15);
             };
+            wait_vm<0>();
+            if (!wr) bar();     // undo the stagger: both groups meet here
+            __syncthreads();    // every wave is done with the ring
+            if (tl) rs[2] = __builtin_readcyclecounter();
 #pragma unroll
             for (int p = 0; p < NPASS; ++p) {
                 size_t orow_q[NCH];
@@ -454,13 +458,24 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs g) {
                 }
                 __syncthreads();
             }
+            if (tl) rs[3] = __builtin_readcyclecounter();
             for (int i = tid; i < C::BM * GR; i += C::NT) {
                 const int trow = i / GR, gi = i - trow * GR;
                 if (!(g.ablate & 8))
                     *(float2*)(g.stats_out + ((size_t)(m0 + trow) * (g.N / 64) + ((n0 >> 6) + gi)) * 2) = *(const float2*)(statbuf + i * 2);
             }
             __syncthreads();
+            if (tl) rs[4] = __builtin_readcyclecounter();
             if (has_next) ring_start();   // restart the ring on the next tile (the issue pointers already point at it)
+            if (tl && g.ln_part && lane == 0 && (wave & 3) == 0) {
+                const int ti = (t - tw.j0) / tw.nloc;
+                if (ti < 16) {
+                    unsigned long long* sp = (unsigned long long*)g.ln_part + (((size_t)blockIdx.x * 2 + wr) * 16 + ti) * 8;
+                    rs[5] = __builtin_readcyclecounter();
+#pragma unroll
+                    for (int i = 0; i < 6; ++i) sp[i] = rs[i];
+                }
+            }
         }
         if (!has_next) break;
         t += tw.nloc;

@@ -1539,7 +1539,7 @@ VP_API int vp_dbg_gemm_bench2(int32_t device, int32_t dtype, int32_t epi, int32_
 // stamps[wg][group][tile < 16][8] = (main loop begin, main loop end, epilogue end, P4 wait of K-tile 0 begin / end, of K-tile 1 begin / end, 0)
 VP_API int vp_dbg_gemm8_timeline(int32_t device, int32_t dtype, int32_t epi, int32_t variant, int32_t flags, int32_t ablate, int32_t M,
                                  int32_t N, int32_t K, uint64_t* stamps, int32_t max_wg) {
-    if ((epi != 0 && epi != 1) || !stamps || max_wg < 256) return fail(nullptr, VP_ERR_INVALID, "bad timeline request");
+    if ((epi != 0 && epi != 1 && epi != vp::EPI_BIAS_RESID_LN) || !stamps || max_wg < 256) return fail(nullptr, VP_ERR_INVALID, "bad timeline request");
     vp_ctx* c = dbg_ctx(device, dtype);
     if (!c) return VP_ERR_HIP;
     RandCase rc;
@@ -1551,8 +1551,11 @@ VP_API int vp_dbg_gemm8_timeline(int32_t device, int32_t dtype, int32_t epi, int
     hipMemset(dS, 0, nst * 8);
     vp::GemmArgs g = rc.g;
     g.variant = variant; g.group_m = 8; g.out = rc.out[0];
+    if (epi == vp::EPI_BIAS_RESID_LN) g.stats_out = rc.stats[0];
     hipError_t e = vp::gemm_launch(c->dtype, epi, g, nullptr);   // warm
-    g.ablate = 32 | ablate; g.stats_out = (float*)dS;
+    g.ablate = 32 | ablate;
+    if (epi == vp::EPI_BIAS_RESID_LN) { g.stats_out = rc.stats[0]; g.ln_part = (const float*)dS; }   // the residual GEMM writes real statistics: stamps go to the unused ln_part
+    else g.stats_out = (float*)dS;
     if (e == hipSuccess) e = vp::gemm_launch(c->dtype, epi, g, nullptr);
     if (e == hipSuccess) e = hipDeviceSynchronize();
     if (e == hipSuccess) e = hipMemcpy(stamps, dS, nst * 8, hipMemcpyDeviceToHost);

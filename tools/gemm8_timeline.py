@@ -14,9 +14,27 @@ from easy_vitpose_amd import _capi as capi
 ap = argparse.ArgumentParser()
 ap.add_argument('--ablate', type=int, default=0)
 ap.add_argument('--batch', type=int, default=256)
+ap.add_argument('--resid', action='store_true', help='the residual GEMMs (attn.proj, mlp.fc2): main loop / drain / passes / statistics / ring restart per tile')
 args = ap.parse_args()
 lib = capi.load_library()
 M, D = args.batch * 192, 768
+if args.resid:
+    for name, N, K, variant, flags in (('proj', D, D, 17, 0), ('fc2', D, 4 * D, 17, 4 | 8)):
+        st = np.zeros((256, 2, 16, 8), dtype=np.uint64)
+        rc = lib.vp_dbg_gemm8_timeline(0, 0, 6, variant, flags, args.ablate, M, N, K, st.ctypes.data_as(C.POINTER(C.c_uint64)), 256)
+        if rc:
+            print(name, 'rc', rc, capi.last_error())
+            continue
+        s = st.astype(np.int64)
+        ntile = int((s[0, 0, :, 0] > 0).sum())
+        t0 = s[:, :, :ntile, :]
+        names = ['main loop', 'drain + re-align', 'staging passes', 'statistics flush', 'ring restart']
+        print(f'{name}: {ntile} tiles per workgroup, medians over 256 workgroups (shader cycles)')
+        for grp in (0, 1):
+            d = np.diff(t0[:, grp, :, :6], axis=2)
+            print(f'  group {grp}: ' + '; '.join(f'{n} {np.median(d[:, :, i], 0).astype(int).tolist()}' for i, n in enumerate(names)))
+        print(f'  launch span {int(t0[:, 0, ntile - 1, 5].max() - t0[:, 0, 0, 0].min())} cycles')
+    sys.exit(0)
 for name, epi, N, flags in (('qkv', 0, 3 * D, 16), ('fc1', 1, 4 * D, 16 | 2)):
     st = np.zeros((256, 2, 16, 8), dtype=np.uint64)
     rc = lib.vp_dbg_gemm8_timeline(0, 0, epi, 16, flags, args.ablate, M, N, D, st.ctypes.data_as(C.POINTER(C.c_uint64)), 256)
