@@ -33,8 +33,10 @@
 //  * W rows are PERMUTED on their way into LDS (free: the source address of a DMA lane is arbitrary) so that the 4 * TI
 //    accumulator values a lane holds for one output row are CONSECUTIVE columns: the 16-bit epilogues (qkv, fc1) store
 //    straight from registers as 16-byte pieces that complete 128-byte lines -- no LDS round trip, no epilogue barrier.
-//  * the residual epilogue (attn.proj / mlp.fc2: + bias + residual planes, two-plane output, LayerNorm row statistics)
-//    stages the tile through LDS exactly like gemm.hip's producer epilogue (bit-identical statistics order).
+//  * the residual epilogue (attn.proj / mlp.fc2: + bias + residual planes, two-plane output, LayerNorm row statistics):
+//    256 x 192 tiles stage the tile through LDS exactly like gemm.hip's producer epilogue; 256 x 256 tiles take it straight
+//    from registers (a row's four lanes are one 64-column statistics granule).  Both replicate gemm.hip's summation tree:
+//    bit-identical statistics.
 //
 // Accumulation order per output element is the same as in gemm.hip (k ascending in steps of 32), so results are
 // bit-identical to the 2-phase kernels: that identity is the race screen (tools/gemm8_check.py, tests).
@@ -47,6 +49,9 @@ namespace vp {
 template <class T, int EPI, class C>
 __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs g) {
     constexpr bool RESID = (EPI == EPI_BIAS_RESID_LN);
+    // residual epilogue: 256-wide tiles take it straight from registers (a lane's 16 accumulator columns of a row are 16 consecutive
+    // output columns and the four lanes of a row are exactly one 64-column statistics granule); 192-wide tiles stage through LDS
+    constexpr bool RESID_LDS = RESID && C::BN != 256;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -292,7 +297,86 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs g) {
         if (tl) ts1 = __builtin_readcyclecounter();
 
         // ---------------- epilogue of tile (m0, n0) ----------------
-        if constexpr (!RESID) {
+        if constexpr (RESID && !RESID_LDS) {
+            // ---- residual epilogue straight from registers (EPI_BIAS_RESID_LN on 256 x 256 tiles) ----
+            // lane (fg, frow): rows m0 + (J >> 2) 128 + wr 64 + (J & 3) 16 + frow, columns nb .. nb + 15 (W rows are permuted on their
+            // way into LDS, see above).  v = acc + bias + (hi + lo) of the residual stream, written back as two 16-bit planes;
+            // LayerNorm partial statistics per (row, 64-column granule): the granule is the four lanes fg = 0..3 of a row, and the
+            // summation tree is gemm.hip's -- per 8-column chunk ((v0+v1)+(v2+v3))+((v4+v5)+(v6+v7)), then chunk pairs, then
+            // pairs of pairs (there: three DPP steps over 8 lanes; here: one add in the lane and two cross-lane adds) -- so the
+            // statistics and everything downstream stay bit-identical to the LDS-staged epilogues.  No LDS, no barrier: the operand
+            // ring runs on across the tile boundary exactly as for the 16-bit epilogues.
+            const int nb = n0 + wc * 64 + fg * 16;
+            const int mrow = m0 + wr * 64 + frow;
+            uint16_t* out_hi = (uint16_t*)g.out;
+            uint16_t* out_lo = out_hi + g.plane;
+            const uint16_t* aux_hi = (const uint16_t*)g.aux;
+            const uint16_t* aux_lo = aux_hi + g.plane;
+            f32x4 bias4[4];
+#pragma unroll
+            for (int f = 0; f < 4; ++f) bias4[f] = *(const f32x4*)(g.bias + nb + f * 4);
+            const bool store = !(g.ablate & 8);
+            const int gran = g.N >> 6;
+            u32x4 res[2][4];   // residual of row group J: hi cols 0-7, hi 8-15, lo 0-7, lo 8-15; fetched one row group ahead
+            auto load_res = [&](int J, u32x4(&r)[4]) {
+                const size_t o = (size_t)(mrow + (J >> 2) * 128 + (J & 3) * 16) * g.ldo + nb;
+                r[0] = *(const u32x4*)(aux_hi + o);
+                r[1] = *(const u32x4*)(aux_hi + o + 8);
+                r[2] = *(const u32x4*)(aux_lo + o);
+                r[3] = *(const u32x4*)(aux_lo + o + 8);
+            };
+            load_res(0, res[0]);
+#pragma unroll
+            for (int J = 0; J < 8; ++J) {
+                if (J + 1 < 8) load_res(J + 1, res[(J + 1) & 1]);
+                const u32x4(&r)[4] = res[J & 1];
+                const int m = mrow + (J >> 2) * 128 + (J & 3) * 16;
+                const size_t o = (size_t)m * g.ldo + nb;
+                float v[16];
+#pragma unroll
+                for (int f = 0; f < 4; ++f) {
+                    const f32x4 st = acc[f][J] + bias4[f];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int c = f * 4 + e;                       // column nb + c
+                        const uint32_t wh = r[c >> 3][(c & 7) >> 1], wl = r[2 + (c >> 3)][(c & 7) >> 1];
+                        const int sh = (c & 1) * 16;
+                        v[c] = st[e] + (from_bits<T>((uint16_t)(wh >> sh)) + from_bits<T>((uint16_t)(wl >> sh)));
+                    }
+                }
+                u32x4 oh[2], ol[2];
+#pragma unroll
+                for (int c = 0; c < 16; c += 2) {   // clamps v to the 16-bit range (the statistics below see the stored value)
+                    uint32_t h_, l_;
+                    split_planes2<T>(v[c], v[c + 1], h_, l_);
+                    oh[c >> 3][(c & 7) >> 1] = h_;
+                    ol[c >> 3][(c & 7) >> 1] = l_;
+                }
+                if (store) {
+                    *(u32x4*)(out_hi + o) = oh[0];
+                    *(u32x4*)(out_hi + o + 8) = oh[1];
+                    *(u32x4*)(out_lo + o) = ol[0];
+                    *(u32x4*)(out_lo + o + 8) = ol[1];
+                }
+                float sa = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+                float sb = ((v[8] + v[9]) + (v[10] + v[11])) + ((v[12] + v[13]) + (v[14] + v[15]));
+                float s1 = sa + sb;
+                s1 += __shfl_xor(s1, 16, 64);
+                s1 += __shfl_xor(s1, 32, 64);
+                const float mg = s1 * (1.0f / 64.0f);
+                float qa = 0.f, qb = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float da = v[e] - mg, db = v[8 + e] - mg;
+                    qa = fmaf(da, da, qa);
+                    qb = fmaf(db, db, qb);
+                }
+                float s2 = qa + qb;
+                s2 += __shfl_xor(s2, 16, 64);
+                s2 += __shfl_xor(s2, 32, 64);
+                if (fg == 0 && store) *(float2*)(g.stats_out + ((size_t)m * gran + (nb >> 6)) * 2) = float2{s1, s2};
+            }
+        } else if constexpr (!RESID) {
             // lane (fg, frow): rows m0 + (J >> 2) 128 + wr 64 + (J & 3) 16 + frow, columns n0 + wc 16 TI + fg 4 TI + [0, 4 TI).
             // Every operand of the epilogue is loaded up front (one latency, not one per row group); the LayerNorm-consumer
             // variant is chosen by ONE wave-uniform branch around the whole block.
@@ -483,7 +567,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs g) {
         n0 = nn0;
     }
     wait_vm<0>();   // the ring's run-ahead DMAs must have landed before the LDS is released
-    if constexpr (!RESID) {
+    if constexpr (!RESID_LDS) {
         if (!wr) bar();   // pair the extra barrier of the staggered group
     }
 }
@@ -491,7 +575,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs g) {
 template <class T, int EPI, class C>
 static hipError_t launch8(const GemmArgs& a, hipStream_t s) {
     auto kern = gemm8_kernel<T, EPI, C>;
-    constexpr int LDS = (EPI == EPI_BIAS_RESID_LN) ? ((128 * (C::BN * 4 + 16) + C::BM * (C::BN / 64) * 8) > C::RING ? (128 * (C::BN * 4 + 16) + C::BM * (C::BN / 64) * 8) : C::RING) : C::RING;
+    constexpr int LDS = (EPI == EPI_BIAS_RESID_LN && C::BN != 256) ? ((128 * (C::BN * 4 + 16) + C::BM * (C::BN / 64) * 8) > C::RING ? (128 * (C::BN * 4 + 16) + C::BM * (C::BN / 64) * 8) : C::RING) : C::RING;
     static bool attr_done[64] = {};   // per device: the LDS opt-in is a per-device function attribute
     int dev = 0;
     (void)hipGetDevice(&dev);
