@@ -41,6 +41,9 @@
 // Accumulation order per output element is the same as in gemm.hip (k ascending in steps of 32), so results are
 // bit-identical to the 2-phase kernels: that identity is the race screen (tools/gemm8_check.py, tests).
 #include "gemm8_common.h"
+#ifndef VP_G8_RESD
+#define VP_G8_RESD 1
+#endif
 
 namespace vp {
 
@@ -317,7 +320,8 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs g) {
             for (int f = 0; f < 4; ++f) bias4[f] = *(const f32x4*)(g.bias + nb + f * 4);
             const bool store = !(g.ablate & 8);
             const int gran = g.N >> 6;
-            u32x4 res[2][4];   // residual of row group J: hi cols 0-7, hi 8-15, lo 0-7, lo 8-15; fetched one row group ahead
+            constexpr int RD = VP_G8_RESD;   // residual of row group J: hi cols 0-7, hi 8-15, lo 0-7, lo 8-15; fetched RD row groups ahead
+            u32x4 res[RD + 1][4];
             auto load_res = [&](int J, u32x4(&r)[4]) {
                 const size_t o = (size_t)(mrow + (J >> 2) * 128 + (J & 3) * 16) * g.ldo + nb;
                 r[0] = *(const u32x4*)(aux_hi + o);
@@ -325,11 +329,12 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs g) {
                 r[2] = *(const u32x4*)(aux_lo + o);
                 r[3] = *(const u32x4*)(aux_lo + o + 8);
             };
-            load_res(0, res[0]);
+#pragma unroll
+            for (int J = 0; J < RD; ++J) load_res(J, res[J]);
 #pragma unroll
             for (int J = 0; J < 8; ++J) {
-                if (J + 1 < 8) load_res(J + 1, res[(J + 1) & 1]);
-                const u32x4(&r)[4] = res[J & 1];
+                if (J + RD < 8) load_res(J + RD, res[(J + RD) % (RD + 1)]);
+                const u32x4(&r)[4] = res[J % (RD + 1)];
                 const int m = mrow + (J >> 2) * 128 + (J & 3) * 16;
                 const size_t o = (size_t)m * g.ldo + nb;
                 float v[16];
