@@ -144,9 +144,10 @@ class VitInference:
         use_tracker = self.is_video and not self.single_pose
         self.tracker = None
         if use_tracker:
-            if self._tracker_factory is None:   # the reference's own choice and parameters (inference.py:182-184)
-                from .tracker import Sort
-                self.tracker = Sort(max_age=self.yolo_step, min_hits=3, iou_threshold=0.3)
+            if self._tracker_factory is None:   # the reference's own choice and parameters (inference.py:179-184):
+                from .tracker import Sort       # with detector-skipped frames (yolo_step > 1) a coasting track's hit streak restarts at every
+                min_hits = 3 if self.yolo_step == 1 else 1   # re-match, so min_hits must be 1 there or no pose is reported on detector frames
+                self.tracker = Sort(max_age=self.yolo_step, min_hits=min_hits, iou_threshold=0.3)
             else:
                 self.tracker = self._tracker_factory()
         self.frame_counter = 0

@@ -5,10 +5,17 @@ CPU side, outside the HIP hot path.  Written from the 
 contract of the reference's tracker so that ``VitInference.inference`` sees the same thing
 (``easy_ViTPose/sort.py:203-266``: ``update(dets[n,5]) -> [m,6] = (x1, y1, x2, y2, score, id)``, ids start at 1, a track is
 reported when it was matched in this frame and has ``min_hits`` consecutive hits or the video is younger than ``min_hits``
-frames, it is dropped after ``max_age`` frames without a match; constructed as ``Sort(max_age=yolo_step, min_hits=3,
-iou_threshold=0.3)`` at ``easy_ViTPose/inference.py:182-184``).  The Kalman filter is the textbook predict / update pair with the
+frames, it is dropped after ``max_age`` frames without a match; constructed as ``Sort(max_age=yolo_step, min_hits=3 if yolo_step == 1 else 1,
+iou_threshold=0.3)`` at ``easy_ViTPose/inference.py:179-184``).  The Kalman filter is the textbook predict / update pair with the
 noise model of the SORT paper's public implementation (R = diag(1, 1, 10, 10), P0 = diag(10 x4, 1e4 x3),
 Q = diag(1, 1, 1, 1, 0.01, 0.01, 1e-4)); no filterpy, no lap.
+
+Two deliberate differences from the reference's tracker, neither visible through ``VitInference``'s contract within one video:
+* track ids restart at 1 for every ``Sort`` instance (``VitInference.reset()`` builds a new one per video); the reference numbers
+  tracks from the class-global ``KalmanBoxTracker.count`` (``sort.py:96,112-113``), which is never reset, so its ids keep growing
+  across ``reset()`` calls and videos;
+* a degenerate (zero-area) detection AND track pair has IoU 0 here; the reference divides 0 by 0 there and its assignment step then
+  raises ``ValueError`` on the NaN.
 """
 from __future__ import annotations
 
@@ -24,7 +31,7 @@ def iou_matrix(dets: np.ndarray, trks: np.ndarray) -> np.ndarray:
     h = np.clip(np.minimum(d[..., 3], t[..., 3]) - np.maximum(d[..., 1], t[..., 1]), 0.0, None)
     inter = w * h
     union = (d[..., 2] - d[..., 0]) * (d[..., 3] - d[..., 1]) + (t[..., 2] - t[..., 0]) * (t[..., 3] - t[..., 1]) - inter
-    return inter / union
+    return np.where(union > 0, inter / np.where(union > 0, union, 1.0), 0.0)   # zero-area pair: IoU 0, not 0 / 0
 
 
 def box_to_z(box) -> np.ndarray:

@@ -116,3 +116,12 @@ def tracker_sequence():
             dets = []                                      # the detector did not run
         frames.append(np.asarray(dets, dtype=np.float64).reshape(-1, 5))
     return frames
+
+
+def tracker_sequence_step(step: int):
+    """The same people as `tracker_sequence`, with the detector run exactly when `VitInference.inference` runs it for
+    `yolo_step = step` (easy_ViTPose/inference.py:235-236: `frame_counter % yolo_step == 0 or frame_counter < 3`) and empty
+    input on every other frame -- the sequence the tracker of a `yolo_step > 1` video sees (constructed with
+    `max_age = step, min_hits = 1`, inference.py:179-184)."""
+    full = tracker_sequence()
+    return [d if (f % step == 0 or f < 3) else np.empty((0, 5)) for f, d in enumerate(full)]

@@ -2,6 +2,7 @@
 """Generate the golden fixtures by running THE REFERENCE ITSELF in this container.
 
     python tests/golden/make_golden.py            # writes tests/golden/*.npz
+    python tests/golden/make_golden.py --only=tracker,outlier     # sections: caller decode model tracker peaked outlier
 
 Runs only where ``/root/reference`` exists (the build container).  The reference
 package is imported read-only with ``sys.dont_write_bytecode`` and with empty stub
@@ -152,134 +153,149 @@ def main():
 
     VitInference, ViTPose, dyn_model_import = import_reference()
     torch.manual_seed(0)
+    only = [a.split('=', 1)[1].split(',') for a in sys.argv[1:] if a.startswith('--only=')]
+    only = set(only[0]) if only else None
+
+    def want(section):   # python tests/golden/make_golden.py --only=tracker,outlier regenerates just those fixtures
+        return only is None or section in only
 
     # ---------------------------------------------------------------- caller goldens
-    # (first: the reference's config modules share one dict, a 'coco' model built after 'wholebody' keeps K = 133)
-    # (1) the reference's pad_image on seeded crops of assorted shapes
-    from easy_ViTPose.vit_utils.inference import pad_image as ref_pad_image
-    from cases import frame_case, pad_shapes
-    rows = []
-    for i, (h, w) in enumerate(pad_shapes()):
-        img = np.random.default_rng(100 + i).integers(0, 256, size=(h, w, 3), dtype=np.uint8)
-        out, (left, top) = ref_pad_image(img, 3 / 4)
-        rows.append([h, w, out.shape[0], out.shape[1], left, top, int(out.astype(np.int64).sum()),
-                     int((out[top:top + h, left:left + w] != img).sum())])
-    np.savez_compressed(os.path.join(HERE, 'pad_image.npz'), rows=np.asarray(rows, dtype=np.int64))
+    if want('caller'):
+        # (first: the reference's config modules share one dict, a 'coco' model built after 'wholebody' keeps K = 133)
+        # (1) the reference's pad_image on seeded crops of assorted shapes
+        from easy_ViTPose.vit_utils.inference import pad_image as ref_pad_image
+        from cases import frame_case, pad_shapes
+        rows = []
+        for i, (h, w) in enumerate(pad_shapes()):
+            img = np.random.default_rng(100 + i).integers(0, 256, size=(h, w, 3), dtype=np.uint8)
+            out, (left, top) = ref_pad_image(img, 3 / 4)
+            rows.append([h, w, out.shape[0], out.shape[1], left, top, int(out.astype(np.int64).sum()),
+                         int((out[top:top + h, left:left + w] != img).sum())])
+        np.savez_compressed(os.path.join(HERE, 'pad_image.npz'), rows=np.asarray(rows, dtype=np.int64))
 
-    # (1b) the reference's flip_back on seeded heatmaps (mirror pairs of COCO-17: 1-2, 3-4, ..., 15-16)
-    from easy_ViTPose.vit_utils.post_processing.post_transforms import flip_back as ref_flip_back
-    from cases import coco_flip_pairs
-    fh = np.random.default_rng(33).standard_normal((2, 17, 64, 48)).astype(np.float32)
-    fb = ref_flip_back(fh.copy(), coco_flip_pairs(), target_type='GaussianHeatmap')
-    print(f'flip_back: oracle-vs-reference max|d| = {np.abs(O.flip_back(fh, coco_flip_pairs()) - fb).max():.3e}')
-    np.savez_compressed(os.path.join(HERE, 'flip_back.npz'), seed=33, expected=np.ascontiguousarray(fb))
+        # (1b) the reference's flip_back on seeded heatmaps (mirror pairs of COCO-17: 1-2, 3-4, ..., 15-16)
+        from easy_ViTPose.vit_utils.post_processing.post_transforms import flip_back as ref_flip_back
+        from cases import coco_flip_pairs
+        fh = np.random.default_rng(33).standard_normal((2, 17, 64, 48)).astype(np.float32)
+        fb = ref_flip_back(fh.copy(), coco_flip_pairs(), target_type='GaussianHeatmap')
+        print(f'flip_back: oracle-vs-reference max|d| = {np.abs(O.flip_back(fh, coco_flip_pairs()) - fb).max():.3e}')
+        np.savez_compressed(os.path.join(HERE, 'flip_back.npz'), seed=33, expected=np.ascontiguousarray(fb))
 
-    # (2) the reference's VitInference.inference(img) end to end on a synthetic frame: a fake detector object with
-    #     the ultralytics result interface feeds the reference's own box loop (inference.py:221-281)
-    frame, boxes = frame_case()
+        # (2) the reference's VitInference.inference(img) end to end on a synthetic frame: a fake detector object with
+        #     the ultralytics result interface feeds the reference's own box loop (inference.py:221-281)
+        frame, boxes = frame_case()
 
-    class _Arr:
-        def __init__(self, a): self.a = a
-        def cpu(self): return self
-        def numpy(self): return self.a
+        class _Arr:
+            def __init__(self, a): self.a = a
+            def cpu(self): return self
+            def numpy(self): return self.a
 
-    class _Res:
-        def __init__(self, a): self.boxes = types.SimpleNamespace(data=_Arr(a))
+        class _Res:
+            def __init__(self, a): self.boxes = types.SimpleNamespace(data=_Arr(a))
 
-    shp = model_shape('s', 'coco')
-    sd = synthetic_state_dict(shp, seed=0)
-    V = build_ref(VitInference, ViTPose, dyn_model_import, 'coco', 's', sd)
-    V.yolo = lambda img, **kw: [_Res(boxes.copy())]
-    V.tracker = None
-    V.frame_counter = 0
-    V.yolo_step = 1
-    V.yolo_size = 320
-    V.yolo_classes = [0]
-    V.save_state = True
-    V._inference = V._inference_torch
-    with torch.no_grad():
-        res = V.inference(frame.copy())
-    ids = sorted(res.keys())
-    kp = np.stack([res[i] for i in ids]).astype(np.float32)
-    tb, tids, tscores = V._tracker_res
-    print(f'frame golden: {len(ids)} persons, padded boxes {np.asarray(tb).tolist()}')
-    np.savez_compressed(os.path.join(HERE, 'frame_inference.npz'), ids=np.asarray(ids), keypoints=kp,
-                        padded_boxes=np.asarray(tb, dtype=np.int64), scores=np.asarray(tscores, dtype=np.float64))
-
-    # ---------------------------------------------------------------- decode goldens
-    for tag, (n, k, seed) in {'decode_k17': (8, 17, 11), 'decode_k133': (2, 133, 12)}.items():
-        hm = peaked_heatmaps(n, k, seed)
-        wh = org_sizes(n, seed)
-        exp = np.concatenate([VitInference.postprocess(hm[i:i + 1].copy(), int(wh[i, 0]), int(wh[i, 1]))
-                              for i in range(n)], 0).astype(np.float32)
-        mine = O.decode_per_crop(hm, wh)
-        print(f'{tag}: oracle-vs-reference max|d| = {np.abs(mine - exp).max():.3e}')
-        np.savez_compressed(os.path.join(HERE, f'{tag}.npz'), n=n, k=k, seed=seed, org_wh=wh, expected=exp)
-
-    # ----------------------------------------------------------------- model goldens
-    # (variant, dataset, n_crops, crop kind, channels kept in the fixture)
-    plan = [('s', 'coco', 2, 'noise', None), ('b', 'coco', 2, 'blobs', None),
-            ('l', 'coco_25', 1, 'blobs', None), ('h', 'wholebody', 1, 'noise', 16)]
-    for variant, dataset, n, kind, keep in plan:
-        shp = model_shape(variant, dataset)
+        shp = model_shape('s', 'coco')
         sd = synthetic_state_dict(shp, seed=0)
-        V = build_ref(VitInference, ViTPose, dyn_model_import, dataset, variant, sd)
-        crops = synthetic_crops(n, seed=7, kind=kind)
-        hms, kps = [], []
+        V = build_ref(VitInference, ViTPose, dyn_model_import, 'coco', 's', sd)
+        V.yolo = lambda img, **kw: [_Res(boxes.copy())]
+        V.tracker = None
+        V.frame_counter = 0
+        V.yolo_step = 1
+        V.yolo_size = 320
+        V.yolo_classes = [0]
+        V.save_state = True
+        V._inference = V._inference_torch
         with torch.no_grad():
-            for i in range(n):
-                x, oh, ow = V.pre_img(crops[i])
-                hms.append(V._vit_pose(torch.from_numpy(x)).numpy())
-                kps.append(V._inference_torch(crops[i]))
-        hms = np.concatenate(hms, 0)
-        kps = np.concatenate(kps, 0).astype(np.float32)
-        sdt = O.to_torch_state_dict(sd)
-        mine_hm = np.concatenate([O.model_forward(sdt, O.pre_img(crops[i])[0], shp.depth, shp.num_heads)
-                                  for i in range(n)], 0)
-        mine_kp = np.concatenate([O.inference_torch(sdt, shp.depth, shp.num_heads, crops[i]) for i in range(n)], 0)
-        print(f'model {variant}/{dataset}: heatmap max|d| = {np.abs(mine_hm - hms).max():.3e} '
-              f'(hm std {hms.std():.3f}), keypoints max|d| = {np.abs(mine_kp - kps).max():.3e}')
-        stats = np.array([hms.mean(), hms.std(), hms.min(), hms.max()], dtype=np.float64)
-        hm_store = hms if keep is None else hms[:, :keep]
-        np.savez_compressed(os.path.join(HERE, f'model_{variant}_{dataset}.npz'), variant=variant, dataset=dataset,
-                            n=n, kind=kind, crop_seed=7, weight_seed=0, heatmaps=hm_store.astype(np.float32),
-                            keypoints=kps, stats=stats)
-
+            res = V.inference(frame.copy())
+        ids = sorted(res.keys())
+        kp = np.stack([res[i] for i in ids]).astype(np.float32)
+        tb, tids, tscores = V._tracker_res
+        print(f'frame golden: {len(ids)} persons, padded boxes {np.asarray(tb).tolist()}')
+        np.savez_compressed(os.path.join(HERE, 'frame_inference.npz'), ids=np.asarray(ids), keypoints=kp,
+                            padded_boxes=np.asarray(tb, dtype=np.int64), scores=np.asarray(tscores, dtype=np.float64))
+    # ---------------------------------------------------------------- decode goldens
+    if want('decode'):
+        for tag, (n, k, seed) in {'decode_k17': (8, 17, 11), 'decode_k133': (2, 133, 12)}.items():
+            hm = peaked_heatmaps(n, k, seed)
+            wh = org_sizes(n, seed)
+            exp = np.concatenate([VitInference.postprocess(hm[i:i + 1].copy(), int(wh[i, 0]), int(wh[i, 1]))
+                                  for i in range(n)], 0).astype(np.float32)
+            mine = O.decode_per_crop(hm, wh)
+            print(f'{tag}: oracle-vs-reference max|d| = {np.abs(mine - exp).max():.3e}')
+            np.savez_compressed(os.path.join(HERE, f'{tag}.npz'), n=n, k=k, seed=seed, org_wh=wh, expected=exp)
+    # ----------------------------------------------------------------- model goldens
+    if want('model'):
+        # (variant, dataset, n_crops, crop kind, channels kept in the fixture)
+        plan = [('s', 'coco', 2, 'noise', None), ('b', 'coco', 2, 'blobs', None),
+                ('l', 'coco_25', 1, 'blobs', None), ('h', 'wholebody', 1, 'noise', 16)]
+        for variant, dataset, n, kind, keep in plan:
+            shp = model_shape(variant, dataset)
+            sd = synthetic_state_dict(shp, seed=0)
+            V = build_ref(VitInference, ViTPose, dyn_model_import, dataset, variant, sd)
+            crops = synthetic_crops(n, seed=7, kind=kind)
+            hms, kps = [], []
+            with torch.no_grad():
+                for i in range(n):
+                    x, oh, ow = V.pre_img(crops[i])
+                    hms.append(V._vit_pose(torch.from_numpy(x)).numpy())
+                    kps.append(V._inference_torch(crops[i]))
+            hms = np.concatenate(hms, 0)
+            kps = np.concatenate(kps, 0).astype(np.float32)
+            sdt = O.to_torch_state_dict(sd)
+            mine_hm = np.concatenate([O.model_forward(sdt, O.pre_img(crops[i])[0], shp.depth, shp.num_heads)
+                                      for i in range(n)], 0)
+            mine_kp = np.concatenate([O.inference_torch(sdt, shp.depth, shp.num_heads, crops[i]) for i in range(n)], 0)
+            print(f'model {variant}/{dataset}: heatmap max|d| = {np.abs(mine_hm - hms).max():.3e} '
+                  f'(hm std {hms.std():.3f}), keypoints max|d| = {np.abs(mine_kp - kps).max():.3e}')
+            stats = np.array([hms.mean(), hms.std(), hms.min(), hms.max()], dtype=np.float64)
+            hm_store = hms if keep is None else hms[:, :keep]
+            np.savez_compressed(os.path.join(HERE, f'model_{variant}_{dataset}.npz'), variant=variant, dataset=dataset,
+                                n=n, kind=kind, crop_seed=7, weight_seed=0, heatmaps=hm_store.astype(np.float32),
+                                keypoints=kps, stats=stats)
     # ------------------------------------------------------- tracker golden (f-4)
-    # the reference's Sort (sort.py:203-266, constructed as inference.py:182-184 does) on a seeded detection sequence: moving
-    # boxes, a missed detection, a late entry, a crossing pair, detector-skipped frames (empty input -> predicted boxes)
-    from easy_ViTPose.sort import Sort as RefSort, KalmanBoxTracker
-    from cases import tracker_sequence
-    for tag, max_age in (('sort_age1', 1), ('sort_age3', 3)):
-        KalmanBoxTracker.count = 0
-        trk = RefSort(max_age=max_age, min_hits=3, iou_threshold=0.3)
-        outs = [np.asarray(trk.update(d.copy()), dtype=np.float64).reshape(-1, 6) for d in tracker_sequence()]
-        flat = np.concatenate([np.concatenate([np.full((len(o), 1), i, dtype=np.float64), o], 1) for i, o in enumerate(outs)])
-        print(f'tracker golden {tag}: {len(outs)} frames, {len(flat)} reported boxes, ids {sorted(set(flat[:, 6].astype(int)))}')
-        np.savez_compressed(os.path.join(HERE, f'{tag}.npz'), rows=flat, max_age=max_age)
-
+    if want('tracker'):
+        # the reference's Sort (sort.py:203-266, constructed as inference.py:182-184 does) on a seeded detection sequence: moving
+        # boxes, a missed detection, a late entry, a crossing pair, detector-skipped frames (empty input -> predicted boxes)
+        from easy_ViTPose.sort import Sort as RefSort, KalmanBoxTracker
+        from cases import tracker_sequence
+        for tag, max_age in (('sort_age1', 1), ('sort_age3', 3)):
+            KalmanBoxTracker.count = 0
+            trk = RefSort(max_age=max_age, min_hits=3, iou_threshold=0.3)
+            outs = [np.asarray(trk.update(d.copy()), dtype=np.float64).reshape(-1, 6) for d in tracker_sequence()]
+            flat = np.concatenate([np.concatenate([np.full((len(o), 1), i, dtype=np.float64), o], 1) for i, o in enumerate(outs)])
+            print(f'tracker golden {tag}: {len(outs)} frames, {len(flat)} reported boxes, ids {sorted(set(flat[:, 6].astype(int)))}')
+            np.savez_compressed(os.path.join(HERE, f'{tag}.npz'), rows=flat, max_age=max_age)
+        # yolo_step > 1 (detector-skipped frames): the reference builds Sort(max_age=step, min_hits=1) there (inference.py:179-184)
+        from cases import tracker_sequence_step
+        for step in (2, 3):
+            KalmanBoxTracker.count = 0
+            trk = RefSort(max_age=step, min_hits=1, iou_threshold=0.3)
+            outs = [np.asarray(trk.update(d.copy()), dtype=np.float64).reshape(-1, 6) for d in tracker_sequence_step(step)]
+            flat = np.concatenate([np.concatenate([np.full((len(o), 1), i, dtype=np.float64), o], 1) for i, o in enumerate(outs)])
+            print(f'tracker golden sort_step{step}: {len(outs)} frames, boxes per frame {[len(o) for o in outs]}')
+            np.savez_compressed(os.path.join(HERE, f'sort_step{step}.npz'), rows=flat, max_age=step, min_hits=1)
     # ------------------------------------------------------- peaked-checkpoint goldens
-    # synthetic_state_dict(peaked=True): one Gaussian-like blob per joint, so the reference's own keypoints are
-    # well-conditioned on EVERY joint and can be asserted end to end (+-0.5 px, 1e-3) on the device.
-    from cases import peaked_plan, peaked_crops
-    for variant, dataset, n in peaked_plan():
-        shp = model_shape(variant, dataset)
-        sd = synthetic_state_dict(shp, seed=0, peaked=True)
-        V = build_ref(VitInference, ViTPose, dyn_model_import, dataset, variant, sd)
-        crops = peaked_crops(n)
-        kps, hm0 = [], None
-        with torch.no_grad():
-            for i in range(n):
-                kps.append(V._inference_torch(crops[i]))
-                if i == 0:
-                    hm0 = V._vit_pose(torch.from_numpy(V.pre_img(crops[0])[0])).numpy()
-        kps = np.concatenate(kps, 0).astype(np.float32)
-        sdt = O.to_torch_state_dict(sd)
-        mine = np.concatenate([O.inference_torch(sdt, shp.depth, shp.num_heads, crops[i]) for i in range(n)], 0)
-        print(f'peaked {variant}/{dataset}: {n} crops x {shp.num_keypoints} joints, confidences {kps[..., 2].min():.3f} .. {kps[..., 2].max():.3f}, '
-              f'oracle-vs-reference keypoints max|d| = {np.abs(mine - kps).max():.3e}')
-        np.savez_compressed(os.path.join(HERE, f'peaked_{variant}_{dataset}.npz'), variant=variant, dataset=dataset, n=n,
-                            keypoints=kps, heatmaps0=hm0[:, :16].astype(np.float32))
+    if want('peaked'):
+        # synthetic_state_dict(peaked=True): one Gaussian-like blob per joint, so the reference's own keypoints are
+        # well-conditioned on EVERY joint and can be asserted end to end (+-0.5 px, 1e-3) on the device.
+        from cases import peaked_plan, peaked_crops
+        for variant, dataset, n in peaked_plan():
+            shp = model_shape(variant, dataset)
+            sd = synthetic_state_dict(shp, seed=0, peaked=True)
+            V = build_ref(VitInference, ViTPose, dyn_model_import, dataset, variant, sd)
+            crops = peaked_crops(n)
+            kps, hm0 = [], None
+            with torch.no_grad():
+                for i in range(n):
+                    kps.append(V._inference_torch(crops[i]))
+                    if i == 0:
+                        hm0 = V._vit_pose(torch.from_numpy(V.pre_img(crops[0])[0])).numpy()
+            kps = np.concatenate(kps, 0).astype(np.float32)
+            sdt = O.to_torch_state_dict(sd)
+            mine = np.concatenate([O.inference_torch(sdt, shp.depth, shp.num_heads, crops[i]) for i in range(n)], 0)
+            print(f'peaked {variant}/{dataset}: {n} crops x {shp.num_keypoints} joints, confidences {kps[..., 2].min():.3f} .. {kps[..., 2].max():.3f}, '
+                  f'oracle-vs-reference keypoints max|d| = {np.abs(mine - kps).max():.3e}')
+            np.savez_compressed(os.path.join(HERE, f'peaked_{variant}_{dataset}.npz'), variant=variant, dataset=dataset, n=n,
+                                keypoints=kps, heatmaps0=hm0[:, :16].astype(np.float32))
 
 
 if __name__ == '__main__':

@@ -268,6 +268,43 @@ def test_tracker_matches_reference_sort(golden_dir, tag):
     assert np.abs(got - z['rows']).max() < 1e-9
 
 
+@pytest.mark.parametrize('step', [2, 3])
+def test_tracker_with_skipped_detector_frames_matches_reference(golden_dir, step):
+    """yolo_step > 1: the reference builds Sort(max_age=step, min_hits=1) (inference.py:179-184) and feeds it empty detections
+    on the frames where the detector is skipped (:235-236).  Same boxes / scores / ids per frame as the reference's Sort --
+    with min_hits = 3 there every detector frame after the third would report NOBODY."""
+    import os
+    from cases import tracker_sequence_step
+    from easy_vitpose_amd.tracker import Sort
+    z = np.load(os.path.join(golden_dir, f'sort_step{step}.npz'))
+    assert int(z['min_hits']) == 1 and int(z['max_age']) == step
+    trk, bad = Sort(max_age=step, min_hits=1, iou_threshold=0.3), Sort(max_age=step, min_hits=3, iou_threshold=0.3)
+    rows, empty_with_3 = [], 0
+    for i, d in enumerate(tracker_sequence_step(step)):
+        o = trk.update(d.copy()).reshape(-1, 6)
+        rows.append(np.concatenate([np.full((len(o), 1), i, dtype=np.float64), o], 1))
+        ob = bad.update(d.copy())
+        empty_with_3 += int(len(d) > 0 and i >= 3 and len(ob) == 0)
+    got = np.concatenate(rows)
+    assert got.shape == z['rows'].shape
+    assert np.array_equal(got[:, [0, 6]], z['rows'][:, [0, 6]])
+    assert np.abs(got - z['rows']).max() < 1e-9
+    assert empty_with_3 > 0          # the failure mode the default must avoid is real on this sequence
+
+
+def test_vitinference_reset_uses_the_references_tracker_parameters():
+    """VitInference.reset(): Sort(max_age=yolo_step, min_hits=3 if yolo_step == 1 else 1, iou_threshold=0.3) -- inference.py:179-184"""
+    from easy_vitpose_amd.inference import VitInference
+    for step, hits in [(1, 3), (2, 1), (5, 1)]:
+        v = VitInference.__new__(VitInference)
+        v.is_video, v.single_pose, v.yolo_step, v._tracker_factory = True, False, step, None
+        v.reset()
+        assert (v.tracker.max_age, v.tracker.min_hits, v.tracker.iou_threshold) == (step, hits, 0.3) and v.frame_counter == 0
+    v.single_pose = True
+    v.reset()
+    assert v.tracker is None
+
+
 def test_tracker_contract():
     from easy_vitpose_amd.tracker import Sort, iou_matrix
     assert Sort().update(np.empty((0, 5))).shape == (0, 6)
@@ -278,6 +315,8 @@ def test_tracker_contract():
     b = t.update(np.empty((0, 5)))                                       # detector skipped: the predicted box comes back
     assert b.shape == (1, 6) and b[0, 5] == 1
     assert abs(iou_matrix(box, box)[0, 0] - 1.0) < 1e-12
+    dot = np.array([[5., 5., 5., 5., 0.5]])
+    assert iou_matrix(dot, dot)[0, 0] == 0.0                             # zero-area pair: 0, not NaN (the reference raises there)
     far = np.array([[400., 400., 450., 500., 0.8]])
     c = t.update(np.concatenate([box, far]))
     assert sorted(c[:, 5].astype(int).tolist()) == [1, 2]
