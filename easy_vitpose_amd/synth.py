@@ -33,7 +33,12 @@ from .configs import IMG_H, IMG_W, ModelShape
 _CODE_NOMINAL = {(384, 12): 18.4, (768, 12): 23.6, (1024, 24): 24.7, (1280, 32): 24.3}
 
 
-def synthetic_state_dict(shape: ModelShape, seed: int = 0, peaked: bool = False) -> "dict[str, np.ndarray]":
+# the same with ``outliers=True`` (the massive channels dominate every row's variance, so the code's LayerNorm output is much smaller;
+# ViTPose-S: calibrated on the peak heights instead -- measured code 1.31 -- so that its confidences stay in 0.25 .. 1.25 as well)
+_CODE_NOMINAL_OUT = {(384, 12): 1.75, (768, 12): 1.866, (1024, 24): 3.474, (1280, 32): 4.898}
+
+
+def synthetic_state_dict(shape: ModelShape, seed: int = 0, peaked: bool = False, outliers: bool = False) -> "dict[str, np.ndarray]":
     """Return ``{name: float32 ndarray}`` with the reference's key names/shapes.
 
     ``peaked=False``: every tensor random (table above) -- heatmaps are noise-like (std ~0.3): right for throughput
@@ -52,7 +57,10 @@ def synthetic_state_dict(shape: ModelShape, seed: int = 0, peaked: bool = False)
       seeded sub-token centre, gain_c = code x the two BatchNorm scales) + a small random part: heatmap k = the bilinear
       interpolation of G_k sampled on the token grid, times the content-dependent LayerNorm gain, plus noise.
 
-    All GEMMs, LayerNorms, the attention and the head still see full-scale random operands; only the read-out is designed."""
+    All GEMMs, LayerNorms, the attention and the head still see full-scale random operands; only the read-out is designed.
+
+    ``outliers=True`` (with or without ``peaked``): the activation statistics of TRAINED ViTs that seeded random tensors lack --
+    "massive activations" in a few residual channels and one attention head with large logits (``_make_outliers``)."""
     rng = np.random.Generator(np.random.PCG64(seed))
     D, L, K = shape.embed_dim, shape.depth, shape.num_keypoints
     sd: dict[str, np.ndarray] = {}
@@ -91,15 +99,63 @@ def synthetic_state_dict(shape: ModelShape, seed: int = 0, peaked: bool = False)
         cin = 256
     sd['keypoint_head.final_layer.weight'] = normal((K, 256, 1, 1), 0.3 / 16.0)
     sd['keypoint_head.final_layer.bias'] = normal((K,), 0.02)
+    if outliers:
+        _make_outliers(sd, shape, seed)
     if peaked:
-        _make_peaked(sd, shape, seed)
+        _make_peaked(sd, shape, seed, outliers)
     return sd
 
 
-def _make_peaked(sd, shape: ModelShape, seed: int) -> None:
+OUTLIER_BLOCK = 3          # the massive channels appear in the residual stream at the end of this block and stay
+OUTLIER_CONST = (800.0, -600.0)   # two channels with a token-independent offset (mlp.fc2 bias)
+OUTLIER_ROW_GAIN = 3.35e5  # / D: two channels driven by the token content (mlp.fc2 weight rows x gain: std ~150, |x| up to ~600)
+LOGIT_TARGET = 45.0        # q and k rows of head 0 of two blocks scaled so that block 1's logits reach this magnitude (>= 30)
+
+
+def outlier_channels(D: int):
+    """Residual channels made massive (outside the 192 position-code channels of the peaked read-out)."""
+    return [D - 5, D - 17, D - 40, D - 77]
+
+
+def _make_outliers(sd, shape: ModelShape, seed: int) -> None:
+    """Trained-ViT-like activation outliers on top of the random tensors (typical residual scale here: 0.3-1):
+
+    * block ``OUTLIER_BLOCK``'s mlp.fc2 writes two channels with a constant +800 / -600 (bias) and two channels whose fc2 weight
+      rows are scaled up (token-dependent values of std ~150, maxima ~600): 100-1000 x the rms of the other channels (0.5-6,
+      measured with the oracle), the regime in which fp16 hi-plane operands, the ``rstd (acc - mean s)`` fold and the row
+      statistics have to stay exact;
+    * head 0 of blocks 1 and ``OUTLIER_BLOCK + 2`` has its q and k projections (weight rows and biases) scaled by the same
+      factor each, chosen so that block 1's logits reach magnitudes of ~45 (>= 30; spread over the keys ~8): a close-to-one-hot
+      softmax for the exp2-softmax and its 16-bit probabilities (the later block, fed by outlier-dominated LayerNorm outputs,
+      reaches 8-20)."""
+    D, L, h = shape.embed_dim, shape.depth, shape.num_heads
+    hd = D // h
+    lo = min(OUTLIER_BLOCK, L - 1)
+    c = outlier_channels(D)
+    p = f'backbone.blocks.{lo}.'
+    amp = min(1.0, float(np.sqrt(D / 768.0)))        # ViTPose-S (D = 384): x 0.71, the same share of a row's variance as in -B
+    sd[p + 'mlp.fc2.bias'][c[0]] += np.float32(OUTLIER_CONST[0] * amp)
+    sd[p + 'mlp.fc2.bias'][c[1]] += np.float32(OUTLIER_CONST[1] * amp)
+    sd[p + 'mlp.fc2.weight'][c[2]] *= np.float32(OUTLIER_ROW_GAIN / D * amp)
+    sd[p + 'mlp.fc2.weight'][c[3]] *= np.float32(OUTLIER_ROW_GAIN / D * amp)
+    # trained models keep such channels out of the read-out with a small last_norm gain; here it keeps the four massive values
+    # (+-20-27 after LayerNorm) from drowning the position code in the deconv head (the blocks' norm1 / norm2 keep gain ~1: the
+    # qkv / fc1 GEMMs DO see them)
+    sd['backbone.last_norm.weight'][c] = np.float32(0.0)
+    sd['backbone.last_norm.bias'][c] = np.float32(0.0)
+    gain = np.float32(np.sqrt(LOGIT_TARGET / (0.009 * D)))   # un-scaled logits of block 1 reach ~0.009 D with these random tensors
+    for blk in sorted({1, min(lo + 2, L - 1)}):
+        p = f'backbone.blocks.{blk}.'
+        for part in (0, 1):                          # q rows, k rows of head 0 (vit.py:166-167: rows [q | k | v] x head x hd)
+            r = slice(part * D, part * D + hd)
+            sd[p + 'attn.qkv.weight'][r] *= gain
+            sd[p + 'attn.qkv.bias'][r] *= gain
+
+
+def _make_peaked(sd, shape: ModelShape, seed: int, outliers: bool = False) -> None:
     D, L, K = shape.embed_dim, shape.depth, shape.num_keypoints
     rng = np.random.Generator(np.random.PCG64(seed + 7777))
-    code = _CODE_NOMINAL.get((D, L), 0.8 * float(np.sqrt(D)))
+    code = (_CODE_NOMINAL_OUT if outliers else _CODE_NOMINAL).get((D, L), 0.8 * float(np.sqrt(D)))
     pos = sd['backbone.pos_embed']
     a = np.float32(2.5 * np.sqrt(D) * np.sqrt(L / 12.0))
     for t in range(192):

@@ -297,6 +297,31 @@ def main():
             np.savez_compressed(os.path.join(HERE, f'peaked_{variant}_{dataset}.npz'), variant=variant, dataset=dataset, n=n,
                                 keypoints=kps, heatmaps0=hm0[:, :16].astype(np.float32))
 
+    # ------------------------------------------------------- peaked checkpoints WITH activation outliers
+    # synthetic_state_dict(peaked=True, outliers=True): the regime of trained ViTs that seeded random tensors lack -- four
+    # residual channels at 100-1000 x the scale of the others from block 3 on (two constant, two token-dependent) and an
+    # attention head with logits of magnitude ~45.  Goldens = the reference's own keypoints, every joint.
+    if want('outlier'):
+        from cases import peaked_plan, peaked_crops
+        for variant, dataset, n in peaked_plan():
+            shp = model_shape(variant, dataset)
+            sd = synthetic_state_dict(shp, seed=0, peaked=True, outliers=True)
+            V = build_ref(VitInference, ViTPose, dyn_model_import, dataset, variant, sd)
+            crops = peaked_crops(n)
+            kps, hm0 = [], None
+            with torch.no_grad():
+                for i in range(n):
+                    kps.append(V._inference_torch(crops[i]))
+                    if i == 0:
+                        hm0 = V._vit_pose(torch.from_numpy(V.pre_img(crops[0])[0])).numpy()
+            kps = np.concatenate(kps, 0).astype(np.float32)
+            sdt = O.to_torch_state_dict(sd)
+            mine = np.concatenate([O.inference_torch(sdt, shp.depth, shp.num_heads, crops[i]) for i in range(n)], 0)
+            print(f'peaked + outliers {variant}/{dataset}: {n} crops x {shp.num_keypoints} joints, confidences {kps[..., 2].min():.3f} .. '
+                  f'{kps[..., 2].max():.3f}, oracle-vs-reference keypoints max|d| = {np.abs(mine - kps).max():.3e}')
+            np.savez_compressed(os.path.join(HERE, f'peaked_outlier_{variant}_{dataset}.npz'), variant=variant, dataset=dataset, n=n,
+                                keypoints=kps, heatmaps0=hm0[:, :16].astype(np.float32))
+
 
 if __name__ == '__main__':
     main()

@@ -111,6 +111,36 @@ def test_peaked_checkpoint_end_to_end_vs_reference_golden(golden_dir, variant, d
     assert dpx.max() < KP_TOL_PX and dcf.max() < CONF_TOL           # in fact all of them
 
 
+@pytest.mark.parametrize('fuse_ln', ['1', '0'])
+@pytest.mark.parametrize('variant,dataset', [('s', 'coco'), ('b', 'coco'), ('l', 'coco_25'), ('h', 'wholebody')])
+def test_outlier_checkpoint_end_to_end_vs_reference_golden(golden_dir, variant, dataset, fuse_ln, monkeypatch):
+    """Trained-ViT-like activation statistics: the peaked checkpoint with four residual channels at 100-1000 x
+    the scale of the others from block 3 on (two constant +800 / -600, two token-dependent with |x| up to ~600) and an attention
+    head whose logits reach ~45.  Goldens = the reference's own `_inference_torch` keypoints; +-0.5 px and 1e-3 on EVERY joint,
+    through the fused-LayerNorm path (fp16 hi plane of the un-normalised rows as the GEMM operand, `rstd (acc - mean s)` fold,
+    granule-merged row statistics) and through the standalone-LayerNorm path (VP_FUSE_LN=0)."""
+    from cases import peaked_crops
+    from easy_vitpose_amd.synth import synthetic_state_dict
+    from easy_vitpose_amd.configs import model_shape
+    monkeypatch.setenv('VP_FUSE_LN', fuse_ln)
+    z = np.load(os.path.join(golden_dir, f'peaked_outlier_{variant}_{dataset}.npz'))
+    n = int(z['n'])
+    shp = model_shape(variant, dataset)
+    eng = VitPoseHip(shp, synthetic_state_dict(shp, 0, peaked=True, outliers=True), dtype='fp16', device_id=0, max_batch=n)
+    crops = peaked_crops(n)
+    kp = eng.infer(crops)
+    hm0 = eng.heatmaps(crops[:1])
+    eng.close()
+    ref = z['keypoints']
+    assert np.isfinite(kp).all() and np.isfinite(hm0).all()
+    dpx = np.abs(kp[..., :2] - ref[..., :2]).max(-1)
+    dcf = np.abs(kp[..., 2] - ref[..., 2])
+    herr = np.abs(hm0[:, :16] - z['heatmaps0'])
+    print(f'[{variant}/outliers, fuse_ln={fuse_ln}] {dpx.size} joints: coordinate max err {dpx.max():.4f} px (mean {dpx.mean():.4f}), '
+          f'confidence max err {dcf.max():.3e} (rms {np.sqrt((dcf ** 2).mean()):.3e}), heatmap max err {herr.max():.3e}')
+    assert dpx.max() < KP_TOL_PX and dcf.max() < CONF_TOL
+
+
 @pytest.mark.parametrize('dtype', ['fp16', 'bf16'])
 @pytest.mark.parametrize('variant,dataset,n', [('s', 'coco', 16), ('b', 'coco', 8)])
 def test_model_parity_vs_oracle(variant, dataset, n, dtype):
