@@ -13,9 +13,11 @@ Workload = BASELINE.json configs[1]: ViTPose-B COCO-17, batch 256, seeded random
 weights of that architecture, synthetic uniform-noise crops.
 
 Prints ONE JSON line on rank 0 with `roofline` (the GEMM family with the largest share of the step, timed live
-with HIP events on the library's stream inside the timed region), `step_ms` percentiles, `host_persons_per_sec`
-(N=1: pinned host buffers -> keypoints on the host through the asynchronous double-buffered entry, PCIe included)
-and `cpu_baseline` (the oracle's torch-CPU per-crop path on this box's host cores, rank 0, N=1 only, bounded sample).
+with HIP events on the library's stream inside the timed region; `kernel` = what the library says it launched, `traffic` read
+from the committed PMC passes as `traffic_source` states), `step_ms` percentiles, `host_persons_per_sec` (N=1: pinned host
+buffers -> keypoints on the host through the asynchronous double-buffered entry, PCIe included), `cpu_baseline` +
+`cpu_baseline_batched` (the oracle's torch-CPU path per crop / in batches of 16 on this box's host cores, rank 0, N=1 only,
+bounded samples), and for N > 1 `per_rank_ms_per_step` / `allgather_ms` / `strong_scaling_config4`.
 """
 from __future__ import annotations
 
@@ -73,61 +75,137 @@ def cpu_baseline(variant, dataset, budget_s=15.0):
                       f'{dt:.1f} s, torch {torch.__version__} with {best_t} threads (best of 8/16/32/64; host has {avail} hw threads)'}
 
 
-# GEMM families of the encoder: profiling-family name -> (kernel symbol prefix in the rocprofv3 trace, description)
+def cpu_baseline_batched(variant, dataset, threads, batch=16, budget_s=12.0):
+    """The batched variant SURVEY.md 8(d) / BASELINE.md section 4 ask for beside the per-crop baseline: the same oracle path on batches
+    of 16 crops (one torch forward per batch, decode per crop like the reference), same thread count as `cpu_baseline` found."""
+    import torch
+    from easy_vitpose_amd.configs import model_shape
+    from easy_vitpose_amd.synth import synthetic_crops, synthetic_state_dict
+    from oracle import vitpose_cpu as O
+    shp = model_shape(variant, dataset)
+    sd = O.to_torch_state_dict(synthetic_state_dict(shp, 0))
+    crops = synthetic_crops(256, 0, 'noise')
+    torch.set_num_threads(threads)
+
+    def run(i0):
+        x = np.concatenate([O.pre_img(c)[0] for c in crops[i0:i0 + batch]])
+        return O.decode_per_crop(O.model_forward(sd, x, shp.depth, shp.num_heads))
+    run(0)
+    n, t0 = 0, time.perf_counter()
+    while n + batch <= len(crops) and (time.perf_counter() - t0 < budget_s or n < batch):
+        run(n)
+        n += batch
+    dt = time.perf_counter() - t0
+    return {'value': round(n / dt, 3), 'unit': 'persons/s', 'cores': threads, 'kind': 'port',
+            'sample': f'{n} crops of the same workload in batches of {batch} (pre_img -> one torch fp32 forward per batch -> decode per crop), '
+                      f'{dt:.1f} s, {threads} threads'}
+
+
+# GEMM families of the encoder (profiling-family name -> what the launch does); the KERNEL a family ran on is reported by the
+# library itself (vp_profile_kernel: the launch code writes the name of the kernel it resolved to)
 FAMILIES = {
-    'gemm_fc1': ('gemm8_kernel<{T}, 1,', 'mlp.fc1 (+LayerNorm fold +bias +GELU), 8-phase persistent kernel, 256x256 tiles'),
-    'gemm_fc2': ('gemm8_kernel<{T}, 6,', 'mlp.fc2 (+bias +residual planes +LayerNorm row statistics), 8-phase kernel, 256x192 tiles'),
-    'gemm_qkv': ('gemm8_kernel<{T}, 0,', 'attn.qkv (+LayerNorm fold +bias), 8-phase persistent kernel, 256x256 tiles'),
-    'gemm_proj': ('gemm_kernel<{T}, 6, 0', 'attn.proj (+bias +residual planes +LayerNorm row statistics), 192x128 tiles'),
+    'gemm_fc1': 'mlp.fc1 (+LayerNorm fold +bias +GELU)',
+    'gemm_fc2': 'mlp.fc2 (+bias +residual planes +LayerNorm row statistics)',
+    'gemm_qkv': 'attn.qkv (+LayerNorm fold +bias)',
+    'gemm_proj': 'attn.proj (+bias +residual planes +LayerNorm row statistics)',
 }
 
 
-def kernel_label(fam, T, B, shp):
-    """Name of the kernel a family runs on at this batch size.  The 8-phase kernel takes a GEMM when its row count is a multiple
-    of 256 and the launch has >= 448 output tiles (vitpose_api.hip: gemm()); smaller launches run gemm_kernel's tile table."""
-    pre, what = FAMILIES[fam]
-    if pre.startswith('gemm8'):
-        M, D = B * 192, shp.embed_dim
-        N = {'gemm_fc1': 4 * D, 'gemm_qkv': 3 * D, 'gemm_fc2': D}[fam]
-        best = None                                   # (fill of the last round of 256 workgroups, tiles, tile width): as vitpose_api.hip gemm()
-        for bn in ((256, 192) if fam == 'gemm_fc2' else (256,)):
-            if N % bn == 0 and M % 256 == 0:
-                t = (M // 256) * (N // bn)
-                f = t / (-(-t // 256) * 256)
-                if best is None or f > best[0] + 1e-9:
-                    best = (f, t, bn)
-        if best is None or not (best[1] >= 448 or (best[0] >= 0.8 and best[1] >= 192)):
-            return f'gemm_kernel<{T}, ...> tile table (shape or launch size outside the set of the 8-phase kernel): ' + what.split(',')[0]
-        what = what.replace('256x192', f'256x{best[2]}')
-    return pre.format(T=T) + ' ...>: ' + what
+class Harness:
+    """The distributed half of the measurement, independent of the HIP engine: one step = local inference on this rank's crops +
+    (world > 1) the all-gather of the keypoints; fence = engine + device + barrier; the timed loop takes the MAX over ranks and
+    also returns every rank's own time and the all-gather's share.  main() builds it around VitPoseHip on cuda:LOCAL_RANK with
+    RCCL; tests/test_parallel_cpu.py drives the SAME code with a fake engine on CPU tensors over gloo (world size 2)."""
+
+    def __init__(self, eng, d_crops, d_out, d_all=None, dist=None, device_sync=None):
+        self.eng, self.d_crops, self.d_out, self.d_all, self.dist = eng, d_crops, d_out, d_all, dist
+        self.device_sync = device_sync or (lambda: None)
+        self.use_dist = dist is not None
+        self.world = dist.get_world_size() if self.use_dist else 1
+        self.rank = dist.get_rank() if self.use_dist else 0
+
+    def step(self):
+        self.eng.infer_device(self.d_crops, self.d_out, sync=self.use_dist)      # library stream; sync hands over to torch's stream
+        if self.use_dist:
+            self.dist.all_gather_into_tensor(self.d_all, self.d_out)             # RCCL over xGMI, [world*B, K, 3]
+
+    def fence(self):
+        self.eng.synchronize()
+        self.device_sync()
+        if self.use_dist:
+            self.dist.barrier()
+
+    def timed(self, steps):
+        """EXACTLY `steps` steps between two fences -> (max-over-ranks seconds, [every rank's seconds])"""
+        import torch
+        self.fence()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            self.step()
+        self.fence()
+        dt = time.perf_counter() - t0
+        if not self.use_dist:
+            return dt, [dt]
+        mine = torch.tensor([dt], dtype=torch.float64, device=self.d_out.device)
+        every = torch.zeros(self.world, dtype=torch.float64, device=self.d_out.device)
+        self.dist.all_gather_into_tensor(every, mine)
+        return float(every.max().item()), [float(v) for v in every.tolist()]
+
+    def allgather_ms(self, reps=20):
+        """the all-gather alone (host-synchronised before and after each one): what of a step is the exchange"""
+        if not self.use_dist:
+            return None
+        self.fence()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            self.dist.all_gather_into_tensor(self.d_all, self.d_out)
+            self.device_sync()
+        return (time.perf_counter() - t0) / reps * 1e3
+
+    def check_gathered(self, n_local):
+        """every rank holds every rank's keypoints; the own shard bit-identical to the local result"""
+        import torch
+        if self.use_dist:
+            assert torch.equal(self.d_all[self.rank * n_local:(self.rank + 1) * n_local], self.d_out), \
+                'all-gather result differs from the local shard'
+        assert torch.isfinite(self.d_out).all(), 'non-finite keypoints'
 
 
-def strong_scaling_config4(world, rank, dev, dtype, steps=100, warmup=10):
-    """BASELINE.json configs[3]: one frame of 64 crops through ViTPose-L coco_25, strong-scaled: every rank takes 64 / world crops
-    (resident in its HBM), RCCL all-gather of the keypoints, max-over-ranks time.  Reported inside the single JSON line as
-    `strong_scaling_config4` (the driver computes efficiency from the per-N values)."""
+def strong_scaling_config4(world, rank, dev, dtype, steps=100, warmup=10, n_total=64, engine_factory=None, dist=None, device_sync=None,
+                           num_keypoints=None):
+    """BASELINE.json configs[3]: one frame of 64 crops through ViTPose-L coco_25, strong-scaled: every rank takes its contiguous shard
+    of the frame (resident in its HBM; ceil(64 / world) crops, the tail rank short or empty when it does not divide), runs it, and ONE
+    all-gather (easy_vitpose_amd.parallel.ShardedPose, pre_sharded) leaves all keypoints on every rank; max-over-ranks time.
+    Reported inside the single JSON line as `strong_scaling_config4` (the driver computes efficiency from the per-N values).
+    `engine_factory(per) -> (engine, local_crops, K)` and `dist` are injectable: the gloo test runs this function with a fake engine."""
     import torch
-    import torch.distributed as dist
-    from easy_vitpose_amd import VitPoseHip
-    from easy_vitpose_amd.configs import model_shape
-    from easy_vitpose_amd.parallel import shard_bounds
-    from easy_vitpose_amd.synth import synthetic_crops, synthetic_state_dict
-    shp = model_shape('l', 'coco_25')
-    N, K = 64, shp.num_keypoints
+    from easy_vitpose_amd.parallel import ShardedPose, shard_bounds
+    if dist is None:
+        import torch.distributed as dist
+    N = n_total
     lo, hi = shard_bounds(N, world, rank)
     per = -(-N // world)
-    eng = VitPoseHip(shp, synthetic_state_dict(shp, 0), dtype=dtype, device_id=dev.index, max_batch=per)
-    crops = torch.from_numpy(synthetic_crops(N, seed=4, kind='noise')[lo:hi]).to(dev)
+    if engine_factory is None:
+        from easy_vitpose_amd import VitPoseHip
+        from easy_vitpose_amd.configs import model_shape
+        from easy_vitpose_amd.synth import synthetic_crops, synthetic_state_dict
+        shp = model_shape('l', 'coco_25')
+        eng = VitPoseHip(shp, synthetic_state_dict(shp, 0), dtype=dtype, device_id=dev.index, max_batch=per)
+        crops = torch.from_numpy(synthetic_crops(N, seed=4, kind='noise')[lo:hi]).to(dev)
+        K = shp.num_keypoints
+        device_sync = device_sync or torch.cuda.synchronize
+    else:
+        eng, crops, K = engine_factory(per, lo, hi)
+        device_sync = device_sync or (lambda: None)
     local = torch.zeros((per, K, 3), dtype=torch.float32, device=dev)
-    gathered = torch.zeros((world * per, K, 3), dtype=torch.float32, device=dev)
+    sp = ShardedPose(lambda shard, wh: eng.infer_device(shard, local[:len(shard)], sync=True), K, device=dev, reuse_buffers=True)
+    out = {}
 
     def frame():
-        if hi > lo:
-            eng.infer_device(crops, local[:hi - lo], sync=True)
-        dist.all_gather_into_tensor(gathered, local)
+        out['kp'] = sp.infer(crops, None, n_total=N, pre_sharded=True)
 
     def fence():
-        eng.synchronize(); torch.cuda.synchronize(); dist.barrier()
+        eng.synchronize(); device_sync(); dist.barrier()
 
     for _ in range(warmup):
         frame()
@@ -136,31 +214,41 @@ def strong_scaling_config4(world, rank, dev, dtype, steps=100, warmup=10):
     for _ in range(steps):
         frame()
     fence()
-    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    mine = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+    every = torch.zeros(world, dtype=torch.float64, device=dev)
+    dist.all_gather_into_tensor(every, mine)
+    kp = out['kp']
+    assert kp.shape == (N, K, 3) and torch.isfinite(kp).all()
+    assert hi == lo or torch.equal(kp[lo:hi], local[:hi - lo]), 'gathered frame differs from the local shard'
     eng.close()
-    dt = float(t.item())
-    return {'workload': 'ViTPose-L coco_25, one frame of 64 u8 crops resident in HBM, 64/world per rank, RCCL all-gather of keypoints',
+    dt = float(every.max().item())
+    return {'workload': f'ViTPose-L coco_25, one frame of {N} u8 crops resident in HBM, ceil({N}/world) per rank, RCCL all-gather of keypoints',
             'scaling': 'strong', 'crops_per_rank': per, 'frames': steps, 'ms_per_frame': round(dt / steps * 1e3, 4),
-            'persons_per_sec': round(N * steps / dt, 1)}
+            'per_rank_ms_per_frame': [round(float(v) / steps * 1e3, 4) for v in every.tolist()],
+            'persons_per_sec': round(N * steps / dt, 1), 'keypoints': kp}
 
 
-def pmc_traffic(args, fam):
-    """HBM bytes per launch of a kernel family from the committed rocprofv3 PMC passes of THIS command (profiles/pmc_r2.json,
-    made by tools/profile.sh + tools/summarize_profile.py; FETCH_SIZE x2 on gfx950 as MI355X_MICROARCH.md prescribes).
-    PMC passes cannot run inside this process, so the figure is read from the committed profile of the same configuration;
-    None when the configuration differs from the profiled one."""
-    path = os.path.join(ROOT, 'profiles', 'pmc_r2.json')
-    if not (os.path.exists(path) and args.variant == 'b' and args.batch == 256 and args.dtype == 'fp16' and args.gpus == 1):
-        return None
-    pre = FAMILIES[fam][0].format(T='F16' if args.dtype == 'fp16' else 'BF16')
+PMC_FILE = os.path.join('profiles', 'pmc_r3.json')
+
+
+def pmc_traffic(args, kernel_name):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of THIS command (PMC_FILE, made by
+    tools/profile.sh + tools/summarize_profile.py; FETCH_SIZE x2 on gfx950 as MI355X_MICROARCH.md prescribes).  PMC passes cannot
+    run inside this process, so the figure is READ from the committed profile of the same configuration -- `roofline.traffic_source`
+    says so in the JSON line; (None, reason) when the configuration differs from the profiled one or the file is absent."""
+    path = os.path.join(ROOT, PMC_FILE)
+    if not (args.variant == 'b' and args.batch == 256 and args.dtype == 'fp16' and args.gpus == 1 and args.dataset == 'coco'):
+        return None, 'not measured: the committed PMC passes are of the default configuration only'
+    if not os.path.exists(path):
+        return None, f'not measured: {PMC_FILE} absent'
+    norm = lambda t: t.replace(' ', '').replace('vp::', '').replace('(anonymousnamespace)::', '')
     try:
         for k, d in json.load(open(path)).items():
-            if k.startswith(pre) and 'hbm_bytes_per_dispatch' in d:
-                return d['hbm_bytes_per_dispatch']
-    except Exception:
-        pass
-    return None
+            if norm(kernel_name) in norm(k) and 'hbm_bytes_per_dispatch' in d:
+                return d['hbm_bytes_per_dispatch'], f'{PMC_FILE} (committed rocprofv3 PMC passes of this command, not measured in this run)'
+    except Exception as e:
+        return None, f'not measured: {PMC_FILE}: {e}'
+    return None, f'not measured: kernel not found in {PMC_FILE}'
 
 
 def host_path_rate(eng, crops_u8, K, seconds=1.5):
@@ -249,16 +337,8 @@ def main():
     d_all = torch.zeros((world * B, K, 3), dtype=torch.float32, device=dev) if use_dist else None
     torch.cuda.synchronize()
 
-    def step():
-        eng.infer_device(d_crops, d_out, sync=use_dist)      # library stream; sync hands over to torch's stream
-        if use_dist:
-            dist.all_gather_into_tensor(d_all, d_out)        # RCCL over xGMI, [world*B, K, 3]
-
-    def fence():
-        eng.synchronize()
-        torch.cuda.synchronize()
-        if use_dist:
-            dist.barrier()
+    H = Harness(eng, d_crops, d_out, d_all, dist if use_dist else None, torch.cuda.synchronize)
+    step, fence = H.step, H.fence
 
     fams = list(FAMILIES)
     eng.set_profiling(fams)      # warm-up pass with all four encoder GEMM families timed: picks the dominant one
@@ -278,21 +358,12 @@ def main():
     if not live:
         for _ in range(3):       # first sighting runs eagerly, the second captures the graph
             step()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    dt = time.perf_counter() - t0
+    dt, per_rank = H.timed(args.steps)              # EXACTLY --steps steps between two fences, max over ranks
     prof = eng.profile() if live else wprof
+    kernels = {f: eng.profile_kernel(f) for f in fams}   # the library's own record of what each family ran on
     eng.set_profiling(False)
-    if use_dist:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-        # every rank holds every rank's keypoints, own shard bit-identical to the local result
-        assert torch.equal(d_all[rank * B:(rank + 1) * B], d_out), 'all-gather result differs from the local shard'
-    assert torch.isfinite(d_out).all(), 'non-finite keypoints'
+    H.check_gathered(B)
+    ag_ms = H.allgather_ms()
 
     # per-step distribution (separate, untimed-for-`value` pass with a host synchronisation after every step)
     step_ms = []
@@ -325,8 +396,9 @@ def main():
         persons_s = world * B * args.steps / dt
         d = prof[dom]
         ach = d['flops'] / (d['ms'] * 1e-3) if d['ms'] > 0 else 0.0
-        T = 'F16' if args.dtype == 'fp16' else 'BF16'
-        per_family = {f: {'ms_per_step': round(wprof[f]['ms'] / max(args.warmup, 1), 4), 'avg_launch_us': round(1e3 * wprof[f]['ms'] / max(wprof[f]['launches'], 1), 2),
+        traffic, traffic_source = pmc_traffic(args, kernels[dom])
+        per_family = {f: {'what': FAMILIES[f], 'kernel': kernels[f],
+                          'ms_per_step': round(wprof[f]['ms'] / max(args.warmup, 1), 4), 'avg_launch_us': round(1e3 * wprof[f]['ms'] / max(wprof[f]['launches'], 1), 2),
                           'tflops': round(wprof[f]['flops'] / max(wprof[f]['ms'], 1e-9) / 1e9, 1),
                           'algorithmic_gbps': round(wprof[f]['bytes'] / max(wprof[f]['ms'], 1e-9) / 1e6, 1)} for f in fams}   # from the warm-up pass
         line = {
@@ -341,9 +413,10 @@ def main():
                        'gflop_per_person': round(shp.gflop_per_person(), 3)},
             'model_tflops': round(persons_s * shp.gflop_per_person() / 1e3, 1),
             'model_frac_of_mfma_peak': round(persons_s * shp.gflop_per_person() * 1e9 / PEAK_MFMA_16BIT, 4),
-            'roofline': {'bound': 'mfma', 'kernel': kernel_label(dom, T, B, shp),
+            'roofline': {'bound': 'mfma', 'kernel': kernels[dom], 'kernel_source': 'vp_profile_kernel (written by the launch code)',
+                         'what': FAMILIES[dom],
                          'achieved': round(ach / 1e12, 2), 'peak': PEAK_MFMA_16BIT / 1e12, 'unit': 'TFLOP/s',
-                         'frac': round(ach / PEAK_MFMA_16BIT, 4), 'traffic': pmc_traffic(args, dom),
+                         'frac': round(ach / PEAK_MFMA_16BIT, 4), 'traffic': traffic, 'traffic_source': traffic_source,
                          'timed': 'live, HIP events around every launch of the timed region' if B > 16 else 'warm-up pass (the timed region replays a hipGraph)',
                          'launches': d['launches'], 'avg_launch_ms': round(d['ms'] / max(d['launches'], 1), 5),
                          'flops_per_launch': d['flops'] / max(d['launches'], 1),
@@ -352,13 +425,19 @@ def main():
             'step_ms': {'p10': round(float(np.percentile(step_ms, 10)), 4), 'p50': round(float(np.percentile(step_ms, 50)), 4),
                         'p90': round(float(np.percentile(step_ms, 90)), 4), 'n': len(step_ms), 'note': 'one host synchronisation per step'},
             'host_persons_per_sec': None if host_rate is None else round(host_rate, 1),
+            # diagnosis of a multi-GPU run: every rank's own time for the same steps, and the exchange alone
+            'per_rank_ms_per_step': [round(v / args.steps * 1e3, 4) for v in per_rank],
+            'allgather_ms': None if ag_ms is None else round(ag_ms, 4),
         }
         if strong is not None:
+            strong.pop('keypoints', None)
             line['strong_scaling_config4'] = strong
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(args.variant, args.dataset)
+            line['cpu_baseline_batched'] = cpu_baseline_batched(args.variant, args.dataset, line['cpu_baseline']['cores'])
         else:
             line['cpu_baseline'] = None
+            line['cpu_baseline_batched'] = None
         print(json.dumps(line), flush=True)
     eng.close()
     if use_dist:

@@ -1,10 +1,17 @@
 """In-tree build of libvitpose_hip.so (gfx950 only) with hipcc.
 
-    python -m easy_vitpose_amd.build [--force]
+    python -m easy_vitpose_amd.build [--force] [--tools]
 
 The shared object is written to ``easy_vitpose_amd/_lib/`` (git-ignored, but it
 travels to the GPU box with the gpurun snapshot).  hipcc cross-compiles for
 gfx950 without a GPU, so this also runs in the CPU-only build container.
+
+Two libraries from the same sources:
+
+* ``libvitpose_hip.so`` -- the PRODUCT: what ``_capi.load_library`` loads, what tests / bench / smoke run.
+* ``libvitpose_hip_tools.so`` (``--tools``, ``-DVP_TOOLS``) -- the measurement build ``tools/`` load through ``VP_HIP_LIB``:
+  ablation flags, start stagger and cycle stamps inside the GEMM kernels, the experimental tile configurations and the
+  deferred-epilogue kernel (``gemm8d.hip``), the development environment switches (``include/vitpose_hip_tools.h``).
 """
 from __future__ import annotations
 
@@ -18,8 +25,11 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIBDIR = os.path.join(HERE, '_lib')
 LIB = os.path.join(LIBDIR, 'libvitpose_hip.so')
-SOURCES = ['gemm.hip', 'gemm8.hip', 'gemm8d.hip', 'attention.hip', 'elementwise.hip', 'decode.hip', 'vitpose_api.hip']
-HEADERS = ['common.h', 'kernels.h', 'gemm8_common.h', os.path.join('..', '..', 'include', 'vitpose_hip.h')]
+TOOLS_LIB = os.path.join(LIBDIR, 'libvitpose_hip_tools.so')
+SOURCES = ['gemm.hip', 'gemm8.hip', 'attention.hip', 'elementwise.hip', 'decode.hip', 'fp8_probe.hip', 'vitpose_api.hip']
+TOOLS_SOURCES = SOURCES + ['gemm8d.hip']
+HEADERS = ['common.h', 'kernels.h', 'gemm8_common.h', os.path.join('..', '..', 'include', 'vitpose_hip.h'),
+           os.path.join('..', '..', 'include', 'vitpose_hip_tools.h')]
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-fvisibility=hidden',
          '-ffp-contract=fast', '-Wno-unused-result']
 
@@ -38,17 +48,19 @@ def _stale(target: str, deps: "list[str]") -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build_library(force: bool = False, verbose: bool = False) -> str:
+def build_library(force: bool = False, verbose: bool = False, tools: bool = False) -> str:
     os.makedirs(LIBDIR, exist_ok=True)
     hipcc = _hipcc()
     hdrs = [os.path.normpath(os.path.join(CSRC, h)) for h in HEADERS]
     objs, jobs = [], []
-    for src in SOURCES:
+    lib = TOOLS_LIB if tools else LIB
+    extra = ['-DVP_TOOLS'] if tools else []
+    for src in (TOOLS_SOURCES if tools else SOURCES):
         s = os.path.join(CSRC, src)
-        o = os.path.join(LIBDIR, src.replace('.hip', '.o'))
+        o = os.path.join(LIBDIR, src.replace('.hip', '.tools.o' if tools else '.o'))
         objs.append(o)
         if force or _stale(o, [s] + hdrs):
-            jobs.append([hipcc, *FLAGS, '-c', s, '-o', o])
+            jobs.append([hipcc, *FLAGS, *extra, '-c', s, '-o', o])
 
     def run(cmd):
         if verbose:
@@ -61,11 +73,11 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     if jobs:
         with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 1)) as ex:
             list(ex.map(run, jobs))
-    if jobs or force or _stale(LIB, objs):
-        run([hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', *objs, '-o', LIB])
-    return LIB
+    if jobs or force or _stale(lib, objs):
+        run([hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', *objs, '-o', lib])
+    return lib
 
 
 if __name__ == '__main__':
-    path = build_library(force='--force' in sys.argv, verbose=True)
+    path = build_library(force='--force' in sys.argv, verbose=True, tools='--tools' in sys.argv)
     print(path)

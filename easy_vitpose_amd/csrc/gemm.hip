@@ -24,6 +24,7 @@
 //    output-parity classes, each a GEMM with K = 4*Cin whose A rows are gathered
 //    (one row chunk per k-step, zero row at the border) straight by the
 //    global_load_lds source addresses -- no im2col buffer in HBM.
+#include <cstdio>
 #include <cstdlib>
 #include <type_traits>
 #include <utility>
@@ -197,7 +198,7 @@ __global__ __launch_bounds__(C::NT, 2) void gemm_kernel(GemmArgs g) {
 #pragma unroll
     for (int p = 0; p < C::AP; ++p) {
         const int r = (p * C::NWAVES + wave) * C::RPG + rip;
-        int m = ((g.ablate & 2) ? 0 : m0) + r;   // ablate 2 (tools): every tile loads the A rows of m-tile 0
+        int m = ((VP_ABLATE(g) & 2) ? 0 : m0) + r;   // ablate 2 (tools): every tile loads the A rows of m-tile 0
         if (m > g.M - 1) m = g.M - 1;
         const int sl = swz<C::BK>(r, pslot) * 8;
         if (AMODE == A_DENSE) {
@@ -333,7 +334,7 @@ __global__ __launch_bounds__(C::NT, 2) void gemm_kernel(GemmArgs g) {
 #pragma unroll
             for (int j = 0; j < C::TJ; ++j) af[j] = *(const u32x4*)(sb + (aoff + j * 16 * C::ROWB));
             if (k + 3 < nk) {
-                if (!(g.ablate & 1)) stage(k + 3, pbuf);
+                if (!(VP_ABLATE(g) & 1)) stage(k + 3, pbuf);
                 wait_vmcnt<2 * C::G>();
             } else if (k + 2 < nk) {
                 wait_vmcnt<C::G>();
@@ -375,7 +376,7 @@ __global__ __launch_bounds__(C::NT, 2) void gemm_kernel(GemmArgs g) {
         else wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();   // every wave's share of tile kt landed; everyone finished tile kt-1
         asm volatile("" ::: "memory");
-        if (kt + C::STAGES - 1 < nk && !(g.ablate & 1)) stage(kt + C::STAGES - 1, pbuf);
+        if (kt + C::STAGES - 1 < nk && !(VP_ABLATE(g) & 1)) stage(kt + C::STAGES - 1, pbuf);
         const char* sb = smem + buf * C::STAGE_BYTES;
         if constexpr (C::PIPE == 5) {
             // reads: per k-half wf[0..TI-1] then af[0..TJ-1] (R = TI + TJ); k-half 0 is issued up front, two
@@ -506,7 +507,7 @@ __global__ __launch_bounds__(C::NT, 2) void gemm_kernel(GemmArgs g) {
 #pragma unroll
         for (int jj = 0; jj < JW; ++jj) {
             const int m = m0 + wave * RPW + jj * 16 + frow;
-            live[jj] = m < g.M && !(g.ablate & 8);
+            live[jj] = m < g.M && !(VP_ABLATE(g) & 8);
             const int t = m / g.Win, jx = m - t * g.Win, ii = t % g.Hin, img = t / g.Hin;
             orow[jj] = (size_t)img * g.Kp * opix + (size_t)(2 * ii + (parity >> 1)) * (2 * g.Win) + 2 * jx + (parity & 1);
         }
@@ -623,7 +624,7 @@ __global__ __launch_bounds__(C::NT, 2) void gemm_kernel(GemmArgs g) {
                     u32x4 oh, ol;
 #pragma unroll
                     for (int e = 0; e < 8; e += 2) { uint32_t h_, l_; split_planes2<T>(v[e], v[e + 1], h_, l_); oh[e >> 1] = h_; ol[e >> 1] = l_; }   // clamps v to the 16-bit range (statistics below see the stored value)
-                    if (!(g.ablate & 8)) {
+                    if (!(VP_ABLATE(g) & 8)) {
                         *(u32x4*)(out_hi + orow_q[q] + n0 + ch * 8) = oh;
                         *(u32x4*)(out_lo + orow_q[q] + n0 + ch * 8) = ol;
                     }
@@ -652,7 +653,7 @@ __global__ __launch_bounds__(C::NT, 2) void gemm_kernel(GemmArgs g) {
         for (int t = tid; t < C::BM * GR; t += C::NT) {
             const int trow = t / GR, gi = t - trow * GR;
             const int m = m0 + trow, n = n0 + gi * 64;
-            if (m < g.M && n < g.N && !(g.ablate & 8))
+            if (m < g.M && n < g.N && !(VP_ABLATE(g) & 8))
                 *(float2*)(g.stats_out + ((size_t)m * (g.N / 64) + (n >> 6)) * 2) = *(const float2*)(statbuf + t * 2);
         }
     } else if constexpr (EPI != EPI_HEATMAP && !C::DIRECT) {
@@ -758,7 +759,7 @@ __global__ __launch_bounds__(C::NT, 2) void gemm_kernel(GemmArgs g) {
                 }
             }
             __syncthreads();
-            if (!(g.ablate & 8)) {
+            if (!(VP_ABLATE(g) & 8)) {
 #pragma unroll
                 for (int q = 0; q < NCH; ++q) {
                     const int c = tid + q * C::NT;
@@ -789,7 +790,7 @@ __global__ __launch_bounds__(C::NT, 2) void gemm_kernel(GemmArgs g) {
 #pragma unroll
         for (int j = 0; j < C::TJ; ++j) {
             const int m = m0 + wm * C::WM + j * 16 + frow;
-            if (m >= g.M || (g.ablate & 8)) continue;
+            if (m >= g.M || (VP_ABLATE(g) & 8)) continue;
             size_t orow;
             if (EPI == EPI_DECONV) {
                 const int t = m / g.Win, jx = m - t * g.Win, ii = t % g.Hin, img = t / g.Hin;
@@ -953,9 +954,9 @@ __global__ __launch_bounds__(C::NT, 2) void gemm_persist_kernel(GemmArgs g) {
         int nm0 = 0, nn0 = 0;
         bool has_next = false;
         unsigned long long ts0 = 0, ts1 = 0, ks[5] = {0, 0, 0, 0, 0};
-        if (g.ablate & 32) ts0 = __builtin_readcyclecounter();   // tools/gemm_timeline.py: per-tile phase stamps of wave 0
+        if (VP_ABLATE(g) & 32) ts0 = __builtin_readcyclecounter();   // tools/gemm_timeline.py: per-tile phase stamps of wave 0
         for (int kt = 0; kt < nk; ++kt) {
-            const bool stamp = (g.ablate & 32) && kt == 5;        // ... and the phases inside k-step 5
+            const bool stamp = (VP_ABLATE(g) & 32) && kt == 5;        // ... and the phases inside k-step 5
             if (stamp) ks[0] = __builtin_readcyclecounter();
             if (kt > 0 || !landed) wait_vmcnt<0>();
             __builtin_amdgcn_s_barrier();
@@ -1004,12 +1005,12 @@ __global__ __launch_bounds__(C::NT, 2) void gemm_persist_kernel(GemmArgs g) {
             if (stamp) ks[4] = __builtin_readcyclecounter();
         }
 
-        if (g.ablate & 32) ts1 = __builtin_readcyclecounter();
+        if (VP_ABLATE(g) & 32) ts1 = __builtin_readcyclecounter();
         // ---- epilogue of tile (m0, n0): bias / LayerNorm consumer / GELU, staged through ring buffer 1 ----
         f32x4 bias4[C::TI], ln_s4[C::TI];
         float ln_mean[C::TJ], ln_rstd[C::TJ];
 #pragma unroll
-        for (int i = 0; i < C::TI; ++i) bias4[i] = (g.ablate & 64) ? f32x4{0.f, 0.f, 0.f, 0.f} : *(const f32x4*)(g.bias + n0 + wn * C::WN + i * 16 + fg * 4);
+        for (int i = 0; i < C::TI; ++i) bias4[i] = (VP_ABLATE(g) & 64) ? f32x4{0.f, 0.f, 0.f, 0.f} : *(const f32x4*)(g.bias + n0 + wn * C::WN + i * 16 + fg * 4);
 #pragma unroll
         for (int i = 0; i < C::TI; ++i) ln_s4[i] = f32x4{0.f, 0.f, 0.f, 0.f};   // neutral fold, see gemm_kernel
 #pragma unroll
@@ -1067,7 +1068,7 @@ __global__ __launch_bounds__(C::NT, 2) void gemm_persist_kernel(GemmArgs g) {
             }
             if (p + 1 < C::TJ / JP) __syncthreads();
         }
-        if ((g.ablate & 32) && tid == 0) {
+        if ((VP_ABLATE(g) & 32) && tid == 0) {
             unsigned long long* st = (unsigned long long*)g.stats_out + ((size_t)blockIdx.x * 32 + (t - j0) / nloc) * 8;
             st[0] = ts0; st[1] = ts1; st[2] = __builtin_readcyclecounter();
 #pragma unroll
@@ -1097,6 +1098,9 @@ static hipError_t launch_persist(const GemmArgs& a, hipStream_t s) {
     int grid = tiles < resident ? tiles : resident;
     grid &= ~7;
     if (grid < 8) return hipErrorInvalidValue;
+    if (a.desc)
+        snprintf(a.desc, a.desc_cap, "gemm_persist_kernel<%s, %d, TileCfg<%d, %d, %d, %d, %d, %d, %d, %d>>", std::is_same<T, F16>::value ? "F16" : "BF16", EPI,
+                 C::BM, C::BN, C::BK, C::WM, C::WN, C::STAGES, C::PIPE, C::DIRECT);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(C::NT), C::LDS, s, a);
     return hipGetLastError();
 }
@@ -1153,29 +1157,39 @@ static hipError_t launch(const GemmArgs& a, hipStream_t s) {
     if ((size_t)tiles_n * C::BN > (size_t)a.w_rows) return hipErrorInvalidValue;   // weight rows are padded at upload
     const int tiles = ((a.M + C::BM - 1) / C::BM) * tiles_n;
     dim3 grid(tiles, AMODE == A_DECONV ? 4 : 1);
+    if (a.desc)
+        snprintf(a.desc, a.desc_cap, "gemm_kernel<%s, %d, %d, TileCfg<%d, %d, %d, %d, %d, %d, %d, %d>>", std::is_same<T, F16>::value ? "F16" : "BF16", EPI,
+                 AMODE, C::BM, C::BN, C::BK, C::WM, C::WN, C::STAGES, C::PIPE, C::DIRECT);
     hipLaunchKernelGGL(kern, grid, dim3(C::NT), LDS_BYTES, s, g);
     return hipGetLastError();
 }
 
+// the product library carries the configurations the selection rule of vitpose_api.hip gemm() can pick (1, 3, 8, 9, 11, 12);
+// the measured alternatives are instantiated in the VP_TOOLS build only
+#ifdef VP_TOOLS
+#define VP_TOOLS_CASE(v) case v: return launch<T, EPI, AMODE, Cfg##v>(a, s);
+#else
+#define VP_TOOLS_CASE(v)
+#endif
 template <class T, int EPI, int AMODE>
 static hipError_t by_variant(const GemmArgs& a, hipStream_t s) {
     switch (a.variant) {
-        case 0: return launch<T, EPI, AMODE, Cfg0>(a, s);
+        VP_TOOLS_CASE(0)
         case 1: return launch<T, EPI, AMODE, Cfg1>(a, s);
-        case 2: return launch<T, EPI, AMODE, Cfg2>(a, s);
+        VP_TOOLS_CASE(2)
         case 3: return launch<T, EPI, AMODE, Cfg3>(a, s);
-        case 4: return launch<T, EPI, AMODE, Cfg4>(a, s);
-        case 5: return launch<T, EPI, AMODE, Cfg5>(a, s);
-        case 6: return launch<T, EPI, AMODE, Cfg6>(a, s);
-        case 7: return launch<T, EPI, AMODE, Cfg7>(a, s);
+        VP_TOOLS_CASE(4)
+        VP_TOOLS_CASE(5)
+        VP_TOOLS_CASE(6)
+        VP_TOOLS_CASE(7)
         case 8: return launch<T, EPI, AMODE, Cfg8>(a, s);
         case 9: return launch<T, EPI, AMODE, Cfg9>(a, s);
-        case 10: return launch<T, EPI, AMODE, Cfg10>(a, s);
+        VP_TOOLS_CASE(10)
         case 11: return launch<T, EPI, AMODE, Cfg11>(a, s);
         case 12: return launch<T, EPI, AMODE, Cfg12>(a, s);
-        case 13: return launch<T, EPI, AMODE, Cfg13>(a, s);
-        case 14: return launch<T, EPI, AMODE, Cfg14>(a, s);
-        case 15: return launch<T, EPI, AMODE, Cfg15>(a, s);
+        VP_TOOLS_CASE(13)
+        VP_TOOLS_CASE(14)
+        VP_TOOLS_CASE(15)
     }
     return hipErrorInvalidValue;
 }
@@ -1209,11 +1223,15 @@ int gemm_tile_bn(int variant) {
 hipError_t gemm_launch(int dtype, int epi, const GemmArgs& a, hipStream_t s) {
     if (a.K % 64 != 0 || a.M <= 0 || a.N <= 0) return hipErrorInvalidValue;
     if (a.variant == 16 || a.variant == 17 || a.variant == 19) {
+#ifdef VP_TOOLS
         static const int stagger_env = [] { const char* e = getenv("VP_G8_STAGGER"); return e ? atoi(e) : -1; }();
-        if (stagger_env < 0) return gemm8_launch(dtype, epi, a, a.variant == 17 ? 192 : 256, s);
-        GemmArgs b = a;   // experiments: override the start stagger
-        b.stagger = stagger_env;
-        return gemm8_launch(dtype, epi, b, a.variant == 17 ? 192 : 256, s);
+        if (stagger_env >= 0) {
+            GemmArgs b = a;   // experiments: override the start stagger
+            b.stagger = stagger_env;
+            return gemm8_launch(dtype, epi, b, a.variant == 17 ? 192 : 256, s);
+        }
+#endif
+        return gemm8_launch(dtype, epi, a, a.variant == 17 ? 192 : 256, s);
     }
     if (a.persist) {   // persistent variant: wide 16-bit-output GEMMs on the default tile (a 256x256 instantiation spilled and was slower)
         if ((epi != EPI_BIAS && epi != EPI_BIAS_GELU) || a.variant != 8 || a.K % 128 || a.N % 8 || a.ldo != a.N || a.reverse ||

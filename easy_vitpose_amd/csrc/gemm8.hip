@@ -40,6 +40,8 @@
 //
 // Accumulation order per output element is the same as in gemm.hip (k ascending in steps of 32), so results are
 // bit-identical to the 2-phase kernels: that identity is the race screen (tools/gemm8_check.py, tests).
+#include <cstdio>
+
 #include "gemm8_common.h"
 #ifndef VP_G8_RESD
 #define VP_G8_RESD 1
@@ -89,17 +91,21 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs g) {
     // DMA of one slot of K-tile kt (of the issue tile) into ring buffer B
     auto issue = [&](int which, int B, int kt, bool force = false) {
         char* dst = smem + B * C::BUF + wave * 1024;
-        if ((g.ablate & 1) && !force) return;
+        if ((VP_ABLATE(g) & 1) && !force) return;
+        // the per-lane offsets pass through an empty asm: every DMA's 64-bit source address is then formed right here, at its use,
+        // instead of eight loop-invariant per-lane pointers being kept live across the phases (which costs 4-11 spilled VGPRs)
+        uint32_t vx = voff_x, vw = voff_w;
+        asm volatile("" : "+v"(vx), "+v"(vw));
         if (which < 2) {   // X half `which`
-            const char* src = xb + (size_t)(which * 2) * x64 + (size_t)kt * xkt + voff_x;
+            const char* src = xb + (size_t)(which * 2) * x64 + (size_t)kt * xkt + vx;
             glds16(src, dst + which * C::HALF);
             glds16(src + x64, dst + which * C::HALF + 8192);
         } else if (which == 2) {
-            const char* src = wb + ((size_t)wu0 * K + (size_t)kt * 64) * 2 + voff_w;
+            const char* src = wb + ((size_t)wu0 * K + (size_t)kt * 64) * 2 + vw;
             glds16(src, dst + C::OFF_W0);
             glds16(src + (size_t)32 * C::TI * K * 2, dst + C::OFF_W0 + 8192);
         } else {
-            const char* src = wb + ((size_t)wu1 * K + (size_t)kt * 64) * 2 + voff_w;
+            const char* src = wb + ((size_t)wu1 * K + (size_t)kt * 64) * 2 + vw;
             glds16(src, dst + C::OFF_W1);
             if (C::NW1 == 2) glds16(src + (size_t)32 * C::TI * K * 2, dst + C::OFF_W1 + 8192);
         }
@@ -268,10 +274,10 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs g) {
         if (wr) bar();   // stagger: waves 4-7 run one barrier behind waves 0-3
     };
 
-    if (g.stagger > 0) {   // experiment (VP_G8_STAGGER): XCD x -- or, from 100 on, workgroup j of every XCD -- starts n * 1024 cycles late so
+    if (VP_STAGGER(g) > 0) {   // experiment (VP_G8_STAGGER): XCD x -- or, from 100 on, workgroup j of every XCD -- starts n * 1024 cycles late so
                            // that the epilogues no longer coincide.  Measured at every step: the launch gets slower by exactly the delay
                            // (the epilogue's cost is per CU, not a shared-bandwidth burst: profiles/gemm8_sections_r2.txt)
-        const int n = (g.stagger >= 100) ? (blockIdx.x >> 3) * (g.stagger - 100) : (blockIdx.x & 7) * g.stagger;   // >= 100: per workgroup inside its XCD
+        const int n = (VP_STAGGER(g) >= 100) ? (blockIdx.x >> 3) * (VP_STAGGER(g) - 100) : (blockIdx.x & 7) * VP_STAGGER(g);   // >= 100: per workgroup inside its XCD
         for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(16);
     }
     // ---- prologue of the first tile: K-tile 0 complete, K-tile 1 in flight ----
@@ -285,7 +291,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs g) {
         const bool has_next = t + tw.nloc < tw.cnt;
         int nm0 = m0, nn0 = n0;   // no next tile: the ring keeps fetching (valid, unused) K-tiles 0 / 1 of this tile
         if (has_next) tw.origin(t + tw.nloc, g.reverse, C::BM, C::BN, nm0, nn0);
-        const bool tl = (g.ablate & 32) != 0;
+        const bool tl = (VP_ABLATE(g) & 32) != 0;
         unsigned long long ts0 = 0, ts1 = 0;
         if (tl) ts0 = __builtin_readcyclecounter();
         ktile(B0{}, M1{}, 2, false, 0, 0, tl ? 0 : -1);
@@ -300,17 +306,20 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs g) {
         if (tl) ts1 = __builtin_readcyclecounter();
 
         // ---------------- epilogue of tile (m0, n0) ----------------
+        // (the same for the epilogue's per-lane offsets: rebuilt per tile from opaque copies of the lane coordinates)
+        int frow_e = frow, fg_e = fg;
+        asm volatile("" : "+v"(frow_e), "+v"(fg_e));
         if constexpr (RESID && !RESID_LDS) {
             // ---- residual epilogue straight from registers (EPI_BIAS_RESID_LN on 256 x 256 tiles) ----
-            // lane (fg, frow): rows m0 + (J >> 2) 128 + wr 64 + (J & 3) 16 + frow, columns nb .. nb + 15 (W rows are permuted on their
+            // lane (fg_e, frow_e): rows m0 + (J >> 2) 128 + wr 64 + (J & 3) 16 + frow_e, columns nb .. nb + 15 (W rows are permuted on their
             // way into LDS, see above).  v = acc + bias + (hi + lo) of the residual stream, written back as two 16-bit planes;
-            // LayerNorm partial statistics per (row, 64-column granule): the granule is the four lanes fg = 0..3 of a row, and the
+            // LayerNorm partial statistics per (row, 64-column granule): the granule is the four lanes fg_e = 0..3 of a row, and the
             // summation tree is gemm.hip's -- per 8-column chunk ((v0+v1)+(v2+v3))+((v4+v5)+(v6+v7)), then chunk pairs, then
             // pairs of pairs (there: three DPP steps over 8 lanes; here: one add in the lane and two cross-lane adds) -- so the
             // statistics and everything downstream stay bit-identical to the LDS-staged epilogues.  No LDS, no barrier: the operand
             // ring runs on across the tile boundary exactly as for the 16-bit epilogues.
-            const int nb = n0 + wc * 64 + fg * 16;
-            const int mrow = m0 + wr * 64 + frow;
+            const int nb = n0 + wc * 64 + fg_e * 16;
+            const int mrow = m0 + wr * 64 + frow_e;
             uint16_t* out_hi = (uint16_t*)g.out;
             uint16_t* out_lo = out_hi + g.plane;
             const uint16_t* aux_hi = (const uint16_t*)g.aux;
@@ -318,7 +327,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs g) {
             f32x4 bias4[4];
 #pragma unroll
             for (int f = 0; f < 4; ++f) bias4[f] = *(const f32x4*)(g.bias + nb + f * 4);
-            const bool store = !(g.ablate & 8);
+            const bool store = !(VP_ABLATE(g) & 8);
             const int gran = g.N >> 6;
             constexpr int RD = VP_G8_RESD;   // residual of row group J: hi cols 0-7, hi 8-15, lo 0-7, lo 8-15; fetched RD row groups ahead
             u32x4 res[RD + 1][4];
@@ -379,14 +388,14 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs g) {
                 float s2 = qa + qb;
                 s2 += __shfl_xor(s2, 16, 64);
                 s2 += __shfl_xor(s2, 32, 64);
-                if (fg == 0 && store) *(float2*)(g.stats_out + ((size_t)m * gran + (nb >> 6)) * 2) = float2{s1, s2};
+                if (fg_e == 0 && store) *(float2*)(g.stats_out + ((size_t)m * gran + (nb >> 6)) * 2) = float2{s1, s2};
             }
         } else if constexpr (!RESID) {
-            // lane (fg, frow): rows m0 + (J >> 2) 128 + wr 64 + (J & 3) 16 + frow, columns n0 + wc 16 TI + fg 4 TI + [0, 4 TI).
+            // lane (fg_e, frow_e): rows m0 + (J >> 2) 128 + wr 64 + (J & 3) 16 + frow_e, columns n0 + wc 16 TI + fg_e 4 TI + [0, 4 TI).
             // Every operand of the epilogue is loaded up front (one latency, not one per row group); the LayerNorm-consumer
             // variant is chosen by ONE wave-uniform branch around the whole block.
-            const int nb = n0 + wc * 16 * C::TI + fg * 4 * C::TI;
-            const int mrow = m0 + wr * 64 + frow;
+            const int nb = n0 + wc * 16 * C::TI + fg_e * 4 * C::TI;
+            const int mrow = m0 + wr * 64 + frow_e;
             auto epilogue = [&](auto LNc) {
                 constexpr bool LN = decltype(LNc)::value;
                 f32x4 bias4[C::TI], s4[LN ? C::TI : 1];
@@ -403,10 +412,10 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs g) {
                     ? (uint16_t*)g.out + (((size_t)(mrow >> 6) * (g.ldo >> 6) + (nb >> 6)) << 12) + ((mrow & 63) << 6) + (nb & 63)
                     : (uint16_t*)g.out + (size_t)mrow * g.ldo + nb;
                 // + 16 rows: blocked 16 * 64 elements (mrow & 63 = wr-independent multiple: rows stay inside one 64-row block
-                // for (J & 3) 16 + frow < 64), + 128 rows: two block rows
+                // for (J & 3) 16 + frow_e < 64), + 128 rows: two block rows
                 const size_t step16 = g.out_blocked ? (size_t)16 * 64 : (size_t)16 * g.ldo;
                 const size_t step128 = g.out_blocked ? ((size_t)2 * (g.ldo >> 6) << 12) : (size_t)128 * g.ldo;
-                const bool store = !(g.ablate & 8);
+                const bool store = !(VP_ABLATE(g) & 8);
 #pragma unroll
                 for (int J = 0; J < 8; ++J) {
                     uint32_t o[2 * C::TI];
@@ -429,7 +438,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs g) {
                     uint16_t* dst = obase + (size_t)(J >> 2) * step128 + (size_t)(J & 3) * step16;
                     if (store) {
                         if constexpr (C::TI == 4) {
-                            if (g.ablate & 64) {   // experiment: streaming (non-temporal) stores
+                            if (VP_ABLATE(g) & 64) {   // experiment: streaming (non-temporal) stores
                                 __builtin_nontemporal_store(u32x4{o[0], o[1], o[2], o[3]}, (u32x4*)dst);
                                 __builtin_nontemporal_store(u32x4{o[4], o[5], o[6], o[7]}, (u32x4*)(dst + 8));
                             } else {
@@ -478,7 +487,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs g) {
             uint16_t* out_lo = out_hi + g.plane;
             const uint16_t* aux_hi = (const uint16_t*)g.aux;
             const uint16_t* aux_lo = aux_hi + g.plane;
-            const int nl = wc * 16 * C::TI + fg * 4 * C::TI;   // first tile column of this lane
+            const int nl = wc * 16 * C::TI + fg_e * 4 * C::TI;   // first tile column of this lane
             f32x4 bias4[C::TI];
 #pragma unroll
             for (int f = 0; f < C::TI; ++f) bias4[f] = *(const f32x4*)(g.bias + n0 + nl + f * 4);
@@ -506,7 +515,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs g) {
                 }
 #pragma unroll
                 for (int jj = 0; jj < JPP; ++jj) {
-                    char* lrow = smem + (wr * 16 * JPP + jj * 16 + frow) * ROWBYTES + nl * 4;
+                    char* lrow = smem + (wr * 16 * JPP + jj * 16 + frow_e) * ROWBYTES + nl * 4;
                     const int J = (p / (4 / JPP)) * 4 + (p % (4 / JPP)) * JPP + jj;
 #pragma unroll
                     for (int f = 0; f < C::TI; ++f) *(f32x4*)(lrow + f * 16) = acc[f][J] + bias4[f];
@@ -529,7 +538,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs g) {
                     u32x4 oh, ol;
 #pragma unroll
                     for (int e = 0; e < 8; e += 2) { uint32_t h_, l_; split_planes2<T>(v[e], v[e + 1], h_, l_); oh[e >> 1] = h_; ol[e >> 1] = l_; }   // clamps v to the 16-bit range (statistics below see the stored value)
-                    if (!(g.ablate & 8)) {
+                    if (!(VP_ABLATE(g) & 8)) {
                         *(u32x4*)(out_hi + orow_q[q] + n0 + ch * 8) = oh;
                         *(u32x4*)(out_lo + orow_q[q] + n0 + ch * 8) = ol;
                     }
@@ -550,7 +559,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs g) {
             if (tl) rs[3] = __builtin_readcyclecounter();
             for (int i = tid; i < C::BM * GR; i += C::NT) {
                 const int trow = i / GR, gi = i - trow * GR;
-                if (!(g.ablate & 8))
+                if (!(VP_ABLATE(g) & 8))
                     *(float2*)(g.stats_out + ((size_t)(m0 + trow) * (g.N / 64) + ((n0 >> 6) + gi)) * 2) = *(const float2*)(statbuf + i * 2);
             }
             __syncthreads();
@@ -593,6 +602,7 @@ static hipError_t launch8(const GemmArgs& a, hipStream_t s) {
     int grid = tiles < 256 ? tiles : 256;
     grid &= ~7;
     if (grid < 8) return hipErrorInvalidValue;
+    if (a.desc) snprintf(a.desc, a.desc_cap, "gemm8_kernel<%s, %d, G8<%d>>", std::is_same<T, F16>::value ? "F16" : "BF16", EPI, C::BN);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(C::NT), LDS, s, a);
     return hipGetLastError();
 }
@@ -610,7 +620,11 @@ bool gemm8_supported(int epi, const GemmArgs& a, int bn) {
 
 hipError_t gemm8_launch(int dtype, int epi, const GemmArgs& a, int bn, hipStream_t s) {
     if (!gemm8_supported(epi, a, bn)) return hipErrorInvalidValue;
-    if (a.variant == 19) return gemm8_deferred_launch(dtype, epi, a, s);   // experimental variant, own translation unit
+#ifdef VP_TOOLS
+    if (a.variant == 19) return gemm8_deferred_launch(dtype, epi, a, s);   // experimental variant, own translation unit (measured, not shipped)
+#else
+    if (a.variant == 19) return hipErrorInvalidValue;
+#endif
 #define VP_G8(TY)                                                                                                       \
     do {                                                                                                                \
         if (epi == EPI_BIAS) return launch8<TY, EPI_BIAS, G8<256>>(a, s);                                               \

@@ -62,7 +62,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_wide_kernel(GemmArgs g) {
     };
     auto issue = [&](int which, int B, int kt, bool force = false) {
         char* dst = smem + B * C::BUF + wave * 1024;
-        if ((g.ablate & 1) && !force) return;
+        if ((VP_ABLATE(g) & 1) && !force) return;
         if (which < 2) {
             const char* src = xb + (size_t)(which * 2) * x64 + (size_t)kt * xkt + voff_x;
             glds16(src, dst + which * C::HALF);
@@ -94,7 +94,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_wide_kernel(GemmArgs g) {
     u32x4 pk11[4];                       // q11 of the previous tile, converted, waiting for its store slot
 #pragma unroll
     for (int j = 0; j < 4; ++j) pk11[j] = u32x4{0, 0, 0, 0};
-    const bool store = !(g.ablate & 8);
+    const bool store = !(VP_ABLATE(g) & 8);
     // 32-bit element offsets into the output (M N < 2^31 is checked by gemm8_supported)
     const uint32_t step16 = g.out_blocked ? 16u * 64u : 16u * (uint32_t)g.ldo;
     const uint32_t step128 = g.out_blocked ? ((2u * (uint32_t)(g.ldo >> 6)) << 12) : 128u * (uint32_t)g.ldo;
@@ -105,7 +105,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_wide_kernel(GemmArgs g) {
                                               : (uint32_t)(wr * 64 + (lane >> 2)) * (uint32_t)g.ldo + (uint32_t)(wc * 64 + (lane & 3) * 8);
     // output element offset of row group 0 of quadrant (hm, hn) of tile (m0, n0) for this lane
     auto out_off = [&](int m0, int n0, int hm, int hn, bool transposed = true) -> uint32_t {
-        if (g.ablate & 128) { m0 = (blockIdx.x & 127) * 256; n0 = 0; }   // experiment: every tile of a workgroup overwrites the same 128 KiB (L2-resident stores)
+        if (VP_ABLATE(g) & 128) { m0 = (blockIdx.x & 127) * 256; n0 = 0; }   // experiment: every tile of a workgroup overwrites the same 128 KiB (L2-resident stores)
         const uint32_t tile_off = g.out_blocked ? (uint32_t)(((m0 >> 6) * (g.ldo >> 6) + (n0 >> 6)) << 12) : (uint32_t)m0 * (uint32_t)g.ldo + (uint32_t)n0;
         return tile_off + (transposed ? lane_off_t : lane_off) + (uint32_t)hm * step128 + (uint32_t)hn * 32u;
     };
@@ -248,8 +248,8 @@ __global__ __launch_bounds__(512, 2) void gemm8_wide_kernel(GemmArgs g) {
         bar();
     };
 
-    if (g.stagger > 0) {   // workgroup j of an XCD starts j * stagger * 64 cycles late: the XCD's store stream is spread over the tile time
-        const int n = (blockIdx.x >> 3) * g.stagger;
+    if (VP_STAGGER(g) > 0) {   // workgroup j of an XCD starts j * stagger * 64 cycles late: the XCD's store stream is spread over the tile time
+        const int n = (blockIdx.x >> 3) * VP_STAGGER(g);
         for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(1);
     }
     if (!ln_in) {   // neutral LayerNorm operands in both areas: s = 0, (mean, rstd) = (0, 1)

@@ -4,6 +4,18 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// Two builds of the same sources (easy_vitpose_amd/build.py): the PRODUCT library (libvitpose_hip.so) and, with -DVP_TOOLS, the
+// measurement library tools/ loads (libvitpose_hip_tools.so): ablation flags and start stagger inside the GEMM loops, cycle
+// stamps, the experimental tile configurations and kernel variants, the development environment switches.  In the product
+// build GemmArgs::ablate / ::stagger read as the constant 0, so none of those branches exists in its kernels.
+#ifdef VP_TOOLS
+#define VP_ABLATE(g) ((g).ablate)
+#define VP_STAGGER(g) ((g).stagger)
+#else
+#define VP_ABLATE(g) 0
+#define VP_STAGGER(g) 0
+#endif
+
 namespace vp {
 
 enum { DT_F16 = 0, DT_BF16 = 1 };
@@ -71,20 +83,32 @@ struct GemmArgs {
     // gemm8.hip: start of XCD x (= blockIdx & 7) delayed by x * stagger * 64 * 127 shader cycles, so that the eight XCDs reach
     // their tile boundaries -- the store bursts of the epilogue -- at different times instead of saturating HBM together
     int stagger;
-    int ablate;           // profiling only (tools/gemm_ablate.py): 1 = no operand loads after the prologue, 2 = every tile loads the A rows of m-tile 0 (A L2-resident), 8 = no epilogue stores
+    int ablate;           // VP_TOOLS builds only (tools/gemm_ablate.py): 1 = no operand loads after the prologue, 2 = every tile loads the A rows of m-tile 0 (A L2-resident), 8 = no epilogue stores
+    char* desc;           // host side: when non-null the launch code writes the resolved kernel's name here (desc_cap bytes)
+    int desc_cap;
 };
 hipError_t gemm_launch(int dtype, int epi, const GemmArgs& a, hipStream_t s);
 // 8-phase persistent kernel (gemm8.hip): 256 x bn tiles (bn = 256 or 192), EPI_BIAS / EPI_BIAS_GELU / EPI_BIAS_RESID_LN.
 // Selected through GemmArgs::variant 16 (bn 256) / 17 (bn 192) in gemm_launch.
 bool gemm8_supported(int epi, const GemmArgs& a, int bn);
 hipError_t gemm8_launch(int dtype, int epi, const GemmArgs& a, int bn, hipStream_t s);
-hipError_t gemm8_deferred_launch(int dtype, int epi, const GemmArgs& a, hipStream_t s);   // gemm8d.hip, variant 19
+#ifdef VP_TOOLS
+hipError_t gemm8_deferred_launch(int dtype, int epi, const GemmArgs& a, hipStream_t s);   // gemm8d.hip, variant 19 (measured, not shipped)
+#endif
+// name of the kernel a launch resolves to, as the profiler prints it minus the namespace; written by the launch code when
+// GemmArgs::desc != nullptr (vp_profile_kernel)
+
 int gemm_tile_bn(int variant);   // BN of a tile configuration (number of n-tiles = ceil(N / BN))
 // fill a 16-bit buffer with pseudo-random values in [-1, 1) (benchmark operands)
 hipError_t fill_random16(int dtype, uint16_t* p, size_t n, uint32_t seed, hipStream_t s);
 
 // partial row statistics [M][tiles][2] (sum, centred M2 per 64-column granule) -> rowstat [M][2] (mean, rstd), LayerNorm eps 1e-6
 hipError_t ln_finalize_launch(const float* partials, float* rowstat, int M, int tiles, int D, hipStream_t s);
+
+// fp8_probe.hip (parity tap of BASELINE config 5): rows of A [M,K] / W [N,K] -> e4m3 codes (x / scale[row]), out = scaled product
+// through v_mfma_f32_16x16x128_f8f6f4
+hipError_t fp8_probe_launch(const float* dA, const float* dW, const float* dAs, const float* dWs, uint8_t* dA8, uint8_t* dW8, float* dOut,
+                            int M, int N, int K, hipStream_t s);
 
 // calibration micro-benchmarks (tools/): kind 0/1 = MFMA 16x16x32 / 32x32x16 f16 TFLOP/s, 2 = float4 copy TB/s
 hipError_t peak_bench(int kind, double* result);

@@ -12,6 +12,9 @@
 #include <vector>
 
 #include "../../include/vitpose_hip.h"
+#ifdef VP_TOOLS
+#include "../../include/vitpose_hip_tools.h"
+#endif
 #include "kernels.h"
 
 namespace {
@@ -91,18 +94,22 @@ struct vp_ctx {
     float *ln_part = nullptr, *rowstat = nullptr;   // partial row statistics [M][D/64][2], (mean, rstd) [M][2]
     // asynchronous host path (vp_infer_submit / vp_infer_wait): two slots, each with its own device staging, so that the
     // H2D of call i+1 and the D2H of call i-1 run on the copy stream under the compute of call i
-    struct Slot { void* in = nullptr; int32_t* wh = nullptr; float* kp = nullptr; hipEvent_t h2d = nullptr, done = nullptr, out = nullptr; bool busy = false; };
+    struct Slot {
+        void* in = nullptr; int32_t* wh = nullptr; float* kp = nullptr; hipEvent_t h2d = nullptr, done = nullptr, out = nullptr; bool busy = false;
+        // staged download (the group path): the D2H lands in this pinned buffer and vp_infer_wait copies it to the caller's `user_out`,
+        // so the submission never blocks on the compute whatever kind of host memory the caller owns
+        float* host_kp = nullptr; float* user_out = nullptr; size_t out_bytes = 0;
+    };
     Slot slots[2];
     hipStream_t copy_stream = nullptr;   // H2D of the asynchronous path
     hipStream_t d2h_stream = nullptr;    // D2H on its own stream: an in-order copy stream would hold the next upload behind `wait compute; download`
     int next_slot = 0;
     // small batches: the whole forward + decode of a chunk captured once per (n, input format, source pointer) into a hipGraph and
     // replayed (170+ launches of a few microseconds each are launch-bound below ~16 crops); VP_GRAPH=0 disables
-    struct GraphEntry { hipGraphExec_t exec = nullptr; int n = 0, fmt = -1, seen = 0; const void* src = nullptr; const int32_t* wh = nullptr; float* out = nullptr; };
+    struct GraphEntry { hipGraphExec_t exec = nullptr; int n = 0, fmt = -1, seen = 0; bool no_graph = false; const void* src = nullptr; const int32_t* wh = nullptr; float* out = nullptr; };
     GraphEntry graphs[4];
     int graph_victim = 0;
     bool fuse_head = true;            // VP_FUSE_HEAD=0: deconv2 and the final 1x1 conv as two launches at every batch size
-    hipGraphExec_t graph_exec = nullptr;   // (unused placeholder kept for vp_destroy)
     int graph_max_n = 16;
     int graph_max_n_stats = 0;        // experiment (VP_FOLD_STATS=1): batches <= 16 crops fold the LayerNorm statistics in the consumer GEMM's epilogue
                                       // instead of 2 x depth ln_finalize launches -- bit-identical, measured SLOWER (L / 8 crops: 3.89 vs 2.97 ms per step)
@@ -119,6 +126,7 @@ struct vp_ctx {
     std::vector<Ev> evs;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
     vp_profile acc{};
+    std::string kernel_desc[VP_PROF_COUNT];   // name of the kernel the last launch of each family resolved to (vp_profile_kernel)
 };
 
 namespace {
@@ -317,6 +325,9 @@ void prof_collect(vp_ctx* c) {
 // Tile configuration per GEMM family.  Defaults = best measured on MI355X (profiles/);
 // experiments override with VP_GEMM_TUNE="fam:variant:group_m,..." (fam = VP_PROF_* index).
 void apply_gemm_tuning(vp_ctx* c) {
+#ifndef VP_TOOLS
+    (void)c;
+#else
     if (const char* t = getenv("VP_GEMM_TUNE")) {
         int f, v, gm, used = 0;
         while (sscanf(t, "%d:%d:%d%n", &f, &v, &gm, &used) == 3) {
@@ -325,6 +336,7 @@ void apply_gemm_tuning(vp_ctx* c) {
             if (*t == ',') ++t; else break;
         }
     }
+#endif
 }
 
 #define LAUNCH(c, fam, flops, bytes, expr)   \
@@ -397,7 +409,11 @@ int gemm(vp_ctx* c, int fam, int epi, const uint16_t* A, const uint16_t* W, cons
         // workgroups best; the kernel is used from 1.75 tiles per CU, or for a smaller launch when its last round is >= 80 % full
         // (measured at batch 32 - 128: ViTPose-B qkv at 216 / 432 tiles -15 % / -5 %, fc2 at 216 tiles -23 %, but fc1 / fc2 at
         // 288 tiles = 56 % full +20 %; ViTPose-H fc2 at batch 128, 480 tiles: 329 -> 279 us)
+#ifdef VP_TOOLS
         static const long min_tiles = [] { const char* e = getenv("VP_G8_MIN_TILES"); return e ? atol(e) : 448L; }();
+#else
+        const long min_tiles = 448;
+#endif
         int bn = 0;
         long tiles = 0;
         double fill = 0.0;
@@ -408,7 +424,10 @@ int gemm(vp_ctx* c, int fam, int epi, const uint16_t* A, const uint16_t* W, cons
             if (f > fill + 1e-9) { bn = cand; tiles = t; fill = f; }
         }
         if (bn && (tiles >= min_tiles || (fill >= 0.8 && tiles >= 192)) && vp::gemm8_supported(epi, g, bn)) {
-            g.variant = bn == 256 ? (wide && c->g8_deferred ? 19 : 16) : 17;
+            g.variant = bn == 256 ? 16 : 17;
+#ifdef VP_TOOLS
+            if (bn == 256 && wide && c->g8_deferred) g.variant = 19;
+#endif
             g.group_m = fam == VP_PROF_GEMM_QKV ? 4 : fam == VP_PROF_GEMM_FC2 ? 2 : 8;   // measured sweep 0 / 2 / 4 / 8 / 16 / 32 (spread 2-3 %)
             g.persist = 0;
             g.stagger = c->g8_stagger;
@@ -437,7 +456,11 @@ int gemm(vp_ctx* c, int fam, int epi, const uint16_t* A, const uint16_t* W, cons
     }
     if (resid) bytes += 4.0 * M * (double)N;
     if (epi == vp::EPI_BIAS_RESID_LN || epi == vp::EPI_POS_LN) bytes += 8.0 * M * (double)(N / 64);   // partial row statistics
+    char desc[192];
+    desc[0] = 0;
+    if (c->prof != 0 || c->kernel_desc[fam].empty()) { g.desc = desc; g.desc_cap = (int)sizeof(desc); }   // the launch code names the kernel it resolved to
     LAUNCH(c, fam, flops, bytes, vp::gemm_launch(c->dtype, epi, g, c->stream));
+    if (desc[0]) c->kernel_desc[fam] = desc;
     return VP_OK;
 }
 
@@ -524,10 +547,11 @@ int decode_chunk(vp_ctx* c, const int32_t* d_wh, float* d_out, int n) {
 // and from then on replayed with one hipGraphLaunch.
 int run_chunk(vp_ctx* c, const void* d_src, int fmt, int nb, const int32_t* d_wh, float* d_out) {
     int rc;
-    if (nb > c->graph_max_n || c->prof != 0) {
+    auto eager = [&]() -> int {
         if ((rc = forward_chunk(c, d_src, fmt, nb, false))) return rc;
         return decode_chunk(c, d_wh, d_out, nb);
-    }
+    };
+    if (nb > c->graph_max_n || c->prof != 0) return eager();
     vp_ctx::GraphEntry* ge = nullptr;
     for (auto& g : c->graphs)
         if (g.n == nb && g.fmt == fmt && g.src == d_src && g.wh == d_wh && g.out == d_out) { ge = &g; break; }
@@ -535,24 +559,38 @@ int run_chunk(vp_ctx* c, const void* d_src, int fmt, int nb, const int32_t* d_wh
         HIPCHK(c, hipGraphLaunch(ge->exec, c->stream));
         return VP_OK;
     }
+    if (ge && ge->no_graph) return eager();   // capture or instantiation failed once for this key: it stays on the eager path
     if (!ge) {   // first sighting: run eagerly (also performs every one-time function-attribute set-up outside a capture), remember the key
         ge = &c->graphs[c->graph_victim++ & 3];
-        if (ge->exec) { hipGraphExecDestroy(ge->exec); ge->exec = nullptr; }
-        ge->n = nb; ge->fmt = fmt; ge->src = d_src; ge->wh = d_wh; ge->out = d_out; ge->seen = 1;
-        if ((rc = forward_chunk(c, d_src, fmt, nb, false))) return rc;
-        return decode_chunk(c, d_wh, d_out, nb);
+        if (ge->exec) {   // eviction: the graph may still be executing on the stream (vp_infer_device with sync = 0)
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            hipGraphExecDestroy(ge->exec);
+            ge->exec = nullptr;
+        }
+        ge->n = nb; ge->fmt = fmt; ge->src = d_src; ge->wh = d_wh; ge->out = d_out; ge->seen = 1; ge->no_graph = false;
+        return eager();
     }
-    // second sighting: capture
+    // second sighting: capture.  Any failure of the capture machinery (not of the launches themselves) marks the key "do not
+    // graph" and the chunk runs eagerly now and from now on -- a handle never gets stuck retrying a capture.
     hipGraph_t graph = nullptr;
-    HIPCHK(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+    hipError_t e = hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal);
+    if (e != hipSuccess) { (void)hipGetLastError(); ge->no_graph = true; return eager(); }
     rc = forward_chunk(c, d_src, fmt, nb, false);
     if (!rc) rc = decode_chunk(c, d_wh, d_out, nb);
-    hipError_t e = hipStreamEndCapture(c->stream, &graph);
-    if (rc) { if (graph) hipGraphDestroy(graph); return rc; }
-    if (e != hipSuccess || !graph) return fail(c, VP_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
-    e = hipGraphInstantiate(&ge->exec, graph, nullptr, nullptr, 0);
-    hipGraphDestroy(graph);
-    if (e != hipSuccess) { ge->exec = nullptr; return fail(c, VP_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e)); }
+    e = hipStreamEndCapture(c->stream, &graph);
+    if (rc) { if (graph) hipGraphDestroy(graph); ge->no_graph = true; return rc; }
+    if (e == hipSuccess && graph) {
+        e = hipGraphInstantiate(&ge->exec, graph, nullptr, nullptr, 0);
+        hipGraphDestroy(graph);
+    } else if (e == hipSuccess) {
+        e = hipErrorUnknown;
+    }
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        ge->exec = nullptr;
+        ge->no_graph = true;
+        return eager();
+    }
     HIPCHK(c, hipGraphLaunch(ge->exec, c->stream));
     return VP_OK;
 }
@@ -610,16 +648,20 @@ int vp_create(vp_handle* out, const vp_config* cfg) {
     if ((rc = dalloc(c, &c->wh_stage, B * 2))) return bail(rc);
     if ((rc = dalloc(c, &c->x, M * D))) return bail(rc);
     if ((rc = dalloc(c, &c->y, M * D))) return bail(rc);
+    // switches between SHIPPED, tested code paths (each has a parity test that flips it): standalone LayerNorm passes, one-tile-per-
+    // workgroup wide GEMMs, eager small batches, un-fused head
     if (const char* f = getenv("VP_FUSE_LN")) c->fuse_ln = atoi(f) != 0;
-    if (const char* f = getenv("VP_BLOCKED_HID")) c->blocked_hid = atoi(f) != 0;
-    if (const char* f = getenv("VP_ORDER")) c->order_mask = atoi(f);
     if (const char* f = getenv("VP_PERSIST")) c->persist_gemm = atoi(f) != 0;
-    if (const char* f = getenv("VP_GEMM8")) c->gemm8_mask = atoi(f);
-    if (const char* f = getenv("VP_G8_STAGGER")) c->g8_stagger = atoi(f);
     if (const char* f = getenv("VP_GRAPH")) c->graph_max_n = atoi(f) == 1 ? 16 : atoi(f);   // 0 = off, 1 = default, n > 1: capture chunks of up to n crops
     if (const char* f = getenv("VP_FUSE_HEAD")) c->fuse_head = atoi(f) != 0;
+#ifdef VP_TOOLS   // development switches of the measurement build (tools/)
+    if (const char* f = getenv("VP_BLOCKED_HID")) c->blocked_hid = atoi(f) != 0;
+    if (const char* f = getenv("VP_ORDER")) c->order_mask = atoi(f);
+    if (const char* f = getenv("VP_GEMM8")) c->gemm8_mask = atoi(f);
+    if (const char* f = getenv("VP_G8_STAGGER")) c->g8_stagger = atoi(f);
     if (const char* f = getenv("VP_FOLD_STATS")) c->graph_max_n_stats = atoi(f) != 0 ? 16 : 0;
     if (const char* f = getenv("VP_G8_DEFERRED")) c->g8_deferred = atoi(f) != 0;
+#endif
     if (c->fuse_ln) {
         if ((rc = dalloc(c, &c->ln_part, M * (size_t)(D / 64) * 2))) return bail(rc);
         if ((rc = dalloc(c, &c->rowstat, M * 2))) return bail(rc);
@@ -772,7 +814,10 @@ void* vp_host_alloc(size_t bytes) {
 }
 void vp_host_free(void* p) { if (p) hipHostFree(p); }
 
-int vp_infer_submit(vp_handle c, const void* crops, int32_t fmt, int32_t n, const int32_t* org_wh, float* out, int32_t* slot_out) {
+// stage_out: the D2H targets the slot's own pinned buffer and vp_infer_wait copies it to `out` (the group path: the caller's
+// memory may be pageable, and an asynchronous copy to pageable memory is host-synchronous -- it would hold the submission until the
+// compute is over and serialise the devices of a group)
+static int submit_impl(vp_handle c, const void* crops, int32_t fmt, int32_t n, const int32_t* org_wh, float* out, int32_t* slot_out, bool stage_out) {
     int rc = check_ready(c, fmt, n, crops, out);
     if (rc) return rc;
     if (!slot_out) return fail(c, VP_ERR_INVALID, "null slot pointer");
@@ -802,12 +847,28 @@ int vp_infer_submit(vp_handle c, const void* crops, int32_t fmt, int32_t n, cons
     HIPCHK(c, hipEventRecord(sl.done, c->stream));
     // download stream: D2H of the keypoints after the compute
     HIPCHK(c, hipStreamWaitEvent(c->d2h_stream, sl.done, 0));
-    HIPCHK(c, hipMemcpyAsync(out, sl.kp, (size_t)n * c->Kp * 12, hipMemcpyDeviceToHost, c->d2h_stream));
+    float* dst = out;
+    sl.user_out = nullptr;
+    if (stage_out) {
+        if (!sl.host_kp) {
+            void* q = nullptr;
+            HIPCHK(c, hipHostMalloc(&q, (size_t)c->maxb * c->Kp * 12, hipHostMallocDefault));
+            sl.host_kp = (float*)q;
+        }
+        dst = sl.host_kp;
+        sl.user_out = out;
+        sl.out_bytes = (size_t)n * c->Kp * 12;
+    }
+    HIPCHK(c, hipMemcpyAsync(dst, sl.kp, (size_t)n * c->Kp * 12, hipMemcpyDeviceToHost, c->d2h_stream));
     HIPCHK(c, hipEventRecord(sl.out, c->d2h_stream));
     sl.busy = true;
     *slot_out = si;
     c->next_slot = si ^ 1;
     return VP_OK;
+}
+
+int vp_infer_submit(vp_handle c, const void* crops, int32_t fmt, int32_t n, const int32_t* org_wh, float* out, int32_t* slot_out) {
+    return submit_impl(c, crops, fmt, n, org_wh, out, slot_out, false);
 }
 
 int vp_infer_wait(vp_handle c, int32_t slot) {
@@ -816,6 +877,7 @@ int vp_infer_wait(vp_handle c, int32_t slot) {
     if (!sl.busy) return fail(c, VP_ERR_STATE, "slot not in flight");
     HIPCHK(c, hipSetDevice(c->cfg.device_id));
     HIPCHK(c, hipEventSynchronize(sl.out));
+    if (sl.user_out) { std::memcpy(sl.user_out, sl.host_kp, sl.out_bytes); sl.user_out = nullptr; }
     sl.busy = false;
     return VP_OK;
 }
@@ -959,6 +1021,7 @@ int vp_decode_only(int32_t device_id, const float* heatmaps, int32_t n, int32_t 
 // ---- multi-GPU group (one process, N devices): crops sharded contiguously, weights replicated ------------------------------
 struct vp_group {
     std::vector<vp_ctx*> h;
+    int peer_missing = 0;        // ordered device pairs without peer access (their all-gather copies are staged through the host)
     std::vector<float*> d_all;   // per device: [max_total, K, 3] keypoints of EVERY shard (vp_group_infer_allgather)
     size_t all_cap = 0;
     std::string err;
@@ -983,16 +1046,19 @@ int vp_group_create(vp_group_handle* out, const vp_config* cfg, const int32_t* d
             if (i != j) {
                 hipSetDevice(device_ids[i]);
                 int can = 0;
+                bool ok = false;
                 if (hipDeviceCanAccessPeer(&can, device_ids[i], device_ids[j]) == hipSuccess && can) {
                     hipError_t e = hipDeviceEnablePeerAccess(device_ids[j], 0);
-                    if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();
+                    ok = e == hipSuccess || e == hipErrorPeerAccessAlreadyEnabled;
                 }
+                if (!ok) { (void)hipGetLastError(); ++g->peer_missing; }   // not fatal: hipMemcpyPeerAsync stages such a pair through the host
             }
     *out = g;
     return VP_OK;
 }
 
 int vp_group_size(vp_group_handle g) { return g ? (int)g->h.size() : 0; }
+int vp_group_peer_access_missing(vp_group_handle g) { return g ? g->peer_missing : -1; }
 
 int vp_group_load_weights(vp_group_handle g, const vp_tensor_desc* tensors, int32_t n_tensors) {
     if (!g) return VP_ERR_INVALID;
@@ -1010,36 +1076,62 @@ static void group_shard(int n, int w, int i, int& off, int& cnt) {
     cnt = n - off < per ? n - off : per;
 }
 
+// the whole plan of a call: rounds of (devices x max_batch) crops, entry e = round * w + device -> [offs[e], offs[e] + cnts[e])
+static int group_plan(int n, int w, int maxb, std::vector<int>& offs, std::vector<int>& cnts) {
+    offs.clear(); cnts.clear();
+    if (n < 0 || w <= 0 || maxb <= 0) return -1;
+    const long per_round = (long)w * maxb;
+    for (long r0 = 0; r0 < n; r0 += per_round) {
+        const int nr = (int)(n - r0 < per_round ? n - r0 : per_round);
+        for (int i = 0; i < w; ++i) {
+            int off, cnt;
+            group_shard(nr, w, i, off, cnt);
+            offs.push_back((int)r0 + off);
+            cnts.push_back(cnt);
+        }
+    }
+    return (int)offs.size();
+}
+
+int vp_dbg_group_plan(int32_t n, int32_t w, int32_t maxb, int32_t* offs, int32_t* cnts, int32_t cap) {
+    std::vector<int> o, k;
+    const int e = group_plan(n, w, maxb, o, k);
+    if (e < 0 || cap < 0 || (cap > 0 && (!offs || !cnts))) return -1;
+    for (int i = 0; i < e && i < cap; ++i) { offs[i] = o[i]; cnts[i] = k[i]; }
+    return e;
+}
+
 static int group_run(vp_group* g, const void* crops, int32_t fmt, int32_t n, const int32_t* org_wh, float* out, float* const* d_all) {
     if (!g || n < 0 || (n > 0 && (!crops || (!out && !d_all)))) return VP_ERR_INVALID;
     const int w = (int)g->h.size();
     const int K = g->h[0]->Kp;
     std::vector<float> scratch;
     if (!out) { scratch.resize((size_t)n * K * 3); out = scratch.data(); }
-    // rounds of (devices x max_batch) crops; inside a round every device works on its shard concurrently (asynchronous submit)
-    const int per_round = w * g->h[0]->maxb;
-    for (int r0 = 0; r0 < n; r0 += per_round) {
-        const int nr = n - r0 < per_round ? n - r0 : per_round;
-        std::vector<int> slot(w, -1), offs(w, 0), cnts(w, 0);
+    std::vector<int> offs, cnts;
+    const int entries = group_plan(n, w, g->h[0]->maxb, offs, cnts);
+    if (entries < 0) return VP_ERR_INVALID;
+    for (int e0 = 0; e0 < entries; e0 += w) {
+        std::vector<int> slot(w, -1);
         // an error leaves no slot of any member in flight: every submitted shard is waited for before the error is returned
         auto drain = [&](int from) { for (int i = from; i < w; ++i) if (slot[i] >= 0) { vp_infer_wait(g->h[i], slot[i]); slot[i] = -1; } };
+        // phase 1 -- enqueue on EVERY member: upload, model, decode, download into the member's pinned staging buffer (and the peer
+        // copies of the device-side all-gather).  Nothing here waits for a device, so all members compute concurrently.
         for (int i = 0; i < w; ++i) {
-            int off, cnt;
-            group_shard(nr, w, i, off, cnt);
-            offs[i] = r0 + off; cnts[i] = cnt;
+            const int off = offs[e0 + i], cnt = cnts[e0 + i];
             if (cnt <= 0) continue;
-            int rc = vp_infer_submit(g->h[i], (const char*)crops + (size_t)offs[i] * crop_bytes(fmt), fmt, cnt,
-                                     org_wh ? org_wh + 2 * (size_t)offs[i] : nullptr, out + (size_t)offs[i] * K * 3, &slot[i]);
-            if (rc) { g->err = g->h[i]->err; slot[i] = -1; drain(0); return rc; }
+            vp_ctx* c = g->h[i];
+            int rc = submit_impl(c, (const char*)crops + (size_t)off * crop_bytes(fmt), fmt, cnt, org_wh ? org_wh + 2 * (size_t)off : nullptr,
+                                 out + (size_t)off * K * 3, &slot[i], true);
+            if (rc) { g->err = c->err; slot[i] = -1; drain(0); return rc; }
             if (d_all) {   // all-gather on the device side: this shard's keypoints to every device's copy, peer to peer, on the owner's stream
-                vp_ctx* c = g->h[i];
                 for (int j = 0; j < w; ++j) {
-                    hipError_t e = hipMemcpyPeerAsync(d_all[j] + (size_t)offs[i] * K * 3, g->h[j]->cfg.device_id, c->slots[slot[i]].kp,
+                    hipError_t e = hipMemcpyPeerAsync(d_all[j] + (size_t)off * K * 3, g->h[j]->cfg.device_id, c->slots[slot[i]].kp,
                                                       c->cfg.device_id, (size_t)cnt * K * 12, c->stream);
                     if (e != hipSuccess) { g->err = std::string("hipMemcpyPeerAsync: ") + hipGetErrorString(e); drain(0); return VP_ERR_HIP; }
                 }
             }
         }
+        // phase 2 -- collect: wait for each member's download, copy its slice to the caller's buffer
         for (int i = 0; i < w; ++i)
             if (slot[i] >= 0) {
                 int rc = vp_infer_wait(g->h[i], slot[i]);
@@ -1103,13 +1195,19 @@ int vp_get_profile(vp_handle c, vp_profile* out) {
     return VP_OK;
 }
 
+int vp_profile_kernel(vp_handle c, int32_t family, char* buf, int32_t cap) {
+    if (!c || family < 0 || family >= VP_PROF_COUNT || !buf || cap <= 0) return VP_ERR_INVALID;
+    snprintf(buf, (size_t)cap, "%s", c->kernel_desc[family].c_str());
+    return VP_OK;
+}
+
 int vp_destroy(vp_handle c) {
     if (!c) return VP_OK;
     hipSetDevice(c->cfg.device_id);
     if (c->stream) hipStreamSynchronize(c->stream);
     for (auto& e : c->evs) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
     for (auto& p : c->ev_pool) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
-    for (auto& sl : c->slots) { if (sl.h2d) hipEventDestroy(sl.h2d); if (sl.done) hipEventDestroy(sl.done); if (sl.out) hipEventDestroy(sl.out); }
+    for (auto& sl : c->slots) { if (sl.h2d) hipEventDestroy(sl.h2d); if (sl.done) hipEventDestroy(sl.done); if (sl.out) hipEventDestroy(sl.out); if (sl.host_kp) hipHostFree(sl.host_kp); }
     if (c->ev_in) hipEventDestroy(c->ev_in);
     if (c->ev_out) hipEventDestroy(c->ev_out);
     for (auto& ge : c->graphs) if (ge.exec) hipGraphExecDestroy(ge.exec);
@@ -1259,8 +1357,7 @@ VP_API int vp_dbg_deconv(int32_t device, int32_t dtype, int32_t B, int32_t Hin, 
 }
 
 
-// Time `iters` launches of one GEMM configuration on random device operands (HIP events).
-// epi as in vp_dbg_gemm (0..3); returns average milliseconds per launch in *ms_out.
+#ifdef VP_TOOLS
 // tools/gemm_timeline.py: one persistent launch of the qkv / fc1 shape with per-tile phase stamps (shader cycles) of wave 0 of
 // every workgroup: stamps[wg][tile][8] = (main loop start, main loop end, epilogue end, 5 stamps inside k-step 5: top, after the
 // barrier, after the global_load_lds issues, after the first MFMA block, end), up to 32 tiles per workgroup.
@@ -1292,7 +1389,10 @@ VP_API int vp_dbg_gemm_timeline(int32_t device, int32_t dtype, int32_t epi, int3
     if (e != hipSuccess) return dbg_finish(c, fail(c, VP_ERR_HIP, std::string("timeline: ") + hipGetErrorString(e)));
     return dbg_finish(c, VP_OK);
 }
+#endif  // VP_TOOLS
 
+// Time `iters` launches of one GEMM configuration on random device operands (HIP events).
+// epi as in vp_dbg_gemm (0..3); returns average milliseconds per launch in *ms_out.
 VP_API int vp_dbg_gemm_bench(int32_t device, int32_t dtype, int32_t epi, int32_t variant, int32_t group_m, int32_t M,
                              int32_t N, int32_t K, int32_t iters, float* ms_out) {
     if (epi < 0 || epi > 3 || M <= 0 || N <= 0 || K <= 0 || K % 64 || iters <= 0 || !ms_out)
@@ -1535,6 +1635,7 @@ VP_API int vp_dbg_gemm_bench2(int32_t device, int32_t dtype, int32_t epi, int32_
     return dbg_finish(c, VP_OK);
 }
 
+#ifdef VP_TOOLS
 // tools/gemm8_timeline.py: one gemm8 launch (variant 16 / 17, epi 0 / 1) with cycle stamps of waves 0 and 4 of every workgroup:
 // stamps[wg][group][tile < 16][8] = (main loop begin, main loop end, epilogue end, P4 wait of K-tile 0 begin / end, of K-tile 1 begin / end, 0)
 VP_API int vp_dbg_gemm8_timeline(int32_t device, int32_t dtype, int32_t epi, int32_t variant, int32_t flags, int32_t ablate, int32_t M,
@@ -1562,6 +1663,7 @@ VP_API int vp_dbg_gemm8_timeline(int32_t device, int32_t dtype, int32_t epi, int
     if (e != hipSuccess) return dbg_finish(c, fail(c, VP_ERR_HIP, std::string("gemm8 timeline: ") + hipGetErrorString(e)));
     return dbg_finish(c, VP_OK);
 }
+#endif  // VP_TOOLS
 
 // run two configurations of the same GEMM on the same random operands `reps` times each and compare every output byte
 // (and the row statistics): the race / schedule screen for kernels whose arithmetic order is identical by construction
@@ -1630,6 +1732,29 @@ VP_API int vp_dbg_crop_prep(int32_t device, const uint8_t* frame, int32_t fh, in
     if (e == hipSuccess) e = hipDeviceSynchronize();
     if (e == hipSuccess) e = hipMemcpy(out, dout, ob, hipMemcpyDeviceToHost);
     if (e != hipSuccess) rc = fail(c, VP_ERR_HIP, std::string("crop_prep: ") + hipGetErrorString(e));
+    return dbg_finish(c, rc);
+}
+
+// BASELINE config 5 probe: rows quantised to OCP e4m3 on device + one GEMM through v_mfma_f32_16x16x128_f8f6f4 (fp8_probe.hip)
+VP_API int vp_dbg_fp8_gemm(int32_t device, int32_t M, int32_t N, int32_t K, const float* A, const float* a_scale, const float* W,
+                           const float* w_scale, float* out, uint8_t* a_codes, uint8_t* w_codes) {
+    if (M <= 0 || N <= 0 || K <= 0 || M % 16 || N % 16 || K % 128 || !A || !W || !a_scale || !w_scale || !out)
+        return fail(nullptr, VP_ERR_INVALID, "bad fp8 probe shape");
+    vp_ctx* c = dbg_ctx(device, VP_DTYPE_F16);
+    if (!c) return VP_ERR_HIP;
+    float *dA, *dW, *dAs, *dWs, *dO;
+    uint8_t *dA8, *dW8;
+    int rc;
+    if ((rc = upload_f32(c, &dA, A, (size_t)M * K)) || (rc = upload_f32(c, &dW, W, (size_t)N * K)) || (rc = upload_f32(c, &dAs, a_scale, M)) ||
+        (rc = upload_f32(c, &dWs, w_scale, N)) || (rc = dalloc(c, &dO, (size_t)M * N)) || (rc = dalloc(c, &dA8, (size_t)M * K)) ||
+        (rc = dalloc(c, &dW8, (size_t)N * K)))
+        return dbg_finish(c, rc);
+    hipError_t e = vp::fp8_probe_launch(dA, dW, dAs, dWs, dA8, dW8, dO, M, N, K, nullptr);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipMemcpy(out, dO, (size_t)M * N * 4, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && a_codes) e = hipMemcpy(a_codes, dA8, (size_t)M * K, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && w_codes) e = hipMemcpy(w_codes, dW8, (size_t)N * K, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) rc = fail(c, VP_ERR_HIP, std::string("fp8 probe: ") + hipGetErrorString(e));
     return dbg_finish(c, rc);
 }
 

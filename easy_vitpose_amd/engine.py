@@ -220,6 +220,12 @@ class VitPoseHip:
         return {name: dict(ms=p.ms[i], flops=p.flops[i], bytes=p.bytes[i], launches=p.launches[i])
                 for i, name in enumerate(capi.VP_PROF_NAMES)}
 
+    def profile_kernel(self, family: str) -> str:
+        """Name of the kernel the last launch of `family` ran on, as the library's launch code recorded it (vp_profile_kernel)."""
+        buf = C.create_string_buffer(256)
+        capi.check(self.lib.vp_profile_kernel(self._h, capi.VP_PROF_NAMES.index(family), buf, len(buf)), self._h)
+        return buf.value.decode('utf-8', 'replace')
+
     def synchronize(self):
         capi.check(self.lib.vp_synchronize(self._h), self._h)
 

@@ -32,7 +32,7 @@ class ShardedPose:
     (or only its own shard with ``pre_sharded=True``) and receives the full ``[N, K, 3]``.
     """
 
-    def __init__(self, infer_local: Callable, num_keypoints: int, device: str = 'cpu', group=None):
+    def __init__(self, infer_local: Callable, num_keypoints: int, device: str = 'cpu', group=None, reuse_buffers: bool = False):
         import torch.distributed as dist
         assert dist.is_initialized(), 'init_process_group first (nccl = RCCL on ROCm, gloo on CPU)'
         self.dist = dist
@@ -42,6 +42,10 @@ class ShardedPose:
         self.infer_local = infer_local
         self.K = num_keypoints
         self.device = device
+        # reuse_buffers: the padded local block and the gathered block are allocated once per shard size and reused by every call (a
+        # frame loop then launches no allocation / fill kernels); the returned tensor is a VIEW that the next call overwrites
+        self.reuse = reuse_buffers
+        self._bufs = {}
 
     def infer(self, crops, org_wh=None, n_total: int | None = None, pre_sharded: bool = False):
         import torch
@@ -56,12 +60,17 @@ class ShardedPose:
             shard = crops[lo:hi]
             wh = None if org_wh is None else org_wh[lo:hi]
         per = -(-n // self.world) if n > 0 else 0
-        local = torch.zeros((per, self.K, 3), dtype=torch.float32, device=self.device)
+        if per not in self._bufs or not self.reuse:
+            self._bufs = {per: (torch.zeros((per, self.K, 3), dtype=torch.float32, device=self.device),
+                                torch.empty((self.world * per, self.K, 3), dtype=torch.float32, device=self.device), [0])}
+        local, gathered, last = self._bufs[per]
+        if hi - lo < last[0]:
+            local[hi - lo:].zero_()          # a shorter shard than last time: the padding rows are zeros again
+        last[0] = hi - lo
         if hi > lo:
             res = self.infer_local(shard, wh)
             res = res if isinstance(res, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(res))
             local[:hi - lo] = res.to(self.device)
-        gathered = torch.empty((self.world * per, self.K, 3), dtype=torch.float32, device=self.device)
         if per > 0:
             # equal-sized (tail rank zero-padded) contributions -> one fused all-gather
             self.dist.all_gather_into_tensor(gathered, local, group=self.group)

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define VP_ABI_VERSION 2
+#define VP_ABI_VERSION 3
 #define VP_API __attribute__((visibility("default")))
 
 /* status codes (0 = ok).  The Python host maps them onto the exception types the
@@ -151,7 +151,16 @@ VP_API int vp_infer_wait(vp_handle h, int32_t slot);
  * each shard is copied peer to peer (hipMemcpyPeerAsync over the xGMI link of the pair) on its owner's stream -- the
  * all-gather of north_star without a collective library in the C ABI (the one-process-per-GPU Python host uses RCCL:
  * easy_vitpose_amd/parallel.py).  `out` may be NULL there.  cfg->device_id is ignored. */
+/* Concurrency: a call enqueues upload + model + decode + download on EVERY member first (the download lands in a
+ * pinned per-member staging buffer, so no member's submission waits for its own compute whatever kind of host memory the
+ * caller passed) and only then waits for the members in turn and copies their slices into `out`.
+ * Ordering of vp_group_infer_allgather: the peer copies into d_all[j] run on the OWNER's private stream; nothing orders them
+ * against work the caller has in flight on device j, so d_all[*] must be idle (already synchronised) when the call starts;
+ * the call returns after every copy has completed (host-synchronised), so consumers need no further ordering.  Pairs without
+ * peer access are not an error (the runtime stages those copies through the host); vp_group_peer_access reports them. */
 VP_API int vp_group_create(vp_group_handle* out, const vp_config* cfg, const int32_t* device_ids, int32_t n_devices);
+/* number of ordered device pairs (i != j) of the group for which peer access could NOT be enabled (0 on an xGMI-connected node) */
+VP_API int vp_group_peer_access_missing(vp_group_handle g);
 VP_API int vp_group_size(vp_group_handle g);
 VP_API vp_handle vp_group_member(vp_group_handle g, int32_t i);
 VP_API int vp_group_load_weights(vp_group_handle g, const vp_tensor_desc* tensors, int32_t n_tensors);
@@ -198,6 +207,11 @@ VP_API int vp_synchronize(vp_handle h);
 VP_API int vp_set_profiling(vp_handle h, int32_t family_mask);
 VP_API int vp_reset_profile(vp_handle h);
 VP_API int vp_get_profile(vp_handle h, vp_profile* out);
+/* Name of the kernel the LAST launch of family `family` (VP_PROF_*) ran on, as the profiler prints it minus the namespace
+ * (e.g. "gemm8_kernel<F16, 1, G8<256>>", "gemm_kernel<F16, 6, 0, TileCfg<192, 128, 64, 48, 64, 2, 1, 0>>"), written by the
+ * launch code itself: bench.py reads `roofline.kernel` from here instead of restating the selection rule.  Empty string when
+ * the family has not been launched yet.  Returns VP_ERR_INVALID for a bad family / NULL buffer. */
+VP_API int vp_profile_kernel(vp_handle h, int32_t family, char* buf, int32_t cap);
 
 VP_API int vp_destroy(vp_handle h);
 
@@ -226,11 +240,6 @@ VP_API int vp_dbg_deconv(int32_t device_id, int32_t dtype, int32_t B, int32_t Hi
 VP_API int vp_dbg_crop_prep(int32_t device_id, const uint8_t* frame, int32_t fh, int32_t fw, const int32_t* crop_params,
                             int32_t n, uint8_t* out);
 /* average milliseconds of `iters` launches of one GEMM tile configuration on random device operands */
-/* tools/gemm_timeline.py: per-tile phase stamps (shader cycles) of one persistent qkv / fc1 launch:
- * stamps[max_wg][32][8] = (main loop start, main loop end, epilogue end, 5 stamps inside k-step 5) of wave 0 of every
- * workgroup. */
-VP_API int vp_dbg_gemm_timeline(int32_t device, int32_t dtype, int32_t epi, int32_t M, int32_t N, int32_t K, uint64_t* stamps,
-                                int32_t max_wg);
 VP_API int vp_dbg_gemm_bench(int32_t device_id, int32_t dtype, int32_t epi, int32_t variant, int32_t group_m,
                              int32_t M, int32_t N, int32_t K, int32_t iters, float* ms_out);
 /* production GEMM configurations on RANDOM device operands (tools/gemm8_check.py, tests/test_gpu_gemm_cfgs.py):
@@ -249,9 +258,18 @@ VP_API int vp_dbg_gemm_bench2(int32_t device_id, int32_t dtype, int32_t epi, int
 VP_API int vp_dbg_gemm_compare(int32_t device_id, int32_t dtype, int32_t epi, int32_t variant_a, int32_t group_a, int32_t flags_a,
                                int32_t variant_b, int32_t group_b, int32_t flags_b, int32_t M, int32_t N, int32_t K, int32_t reps,
                                uint64_t* n_mismatch, double* max_abs_diff);
-/* tools/gemm8_timeline.py: cycle stamps of one gemm8 launch, stamps[max_wg >= 256][2 wave groups][16 tiles][8] */
-VP_API int vp_dbg_gemm8_timeline(int32_t device_id, int32_t dtype, int32_t epi, int32_t variant, int32_t flags, int32_t ablate,
-                                 int32_t M, int32_t N, int32_t K, uint64_t* stamps, int32_t max_wg);
+/* The sharding plan of vp_group_infer for n crops on w devices of max_batch maxb -- HOST ONLY, no device needed: the exact
+ * function group_run executes.  Rounds of w * maxb crops; inside a round device i takes [off, off + cnt) with ceil(nr / w) crops
+ * per device (trailing devices short or empty).  Entry e = round * w + device: offs[e], cnts[e].  Returns the number of
+ * entries (rounds * w), also when it exceeds `cap` (nothing is written beyond cap); < 0 on bad arguments. */
+VP_API int vp_dbg_group_plan(int32_t n, int32_t w, int32_t maxb, int32_t* offs, int32_t* cnts, int32_t cap);
+/* BASELINE config 5 probe (fp8 is documented tolerance-infeasible; this confirms the CPU emulation the
+ * finding rests on, tests/fp8_budget.py, on the hardware): rows of A [M,K] and W [N,K] are quantised on device to OCP e4m3
+ * (x / scale[row], v_cvt_pk_fp8_f32) and multiplied through v_mfma_f32_16x16x128_f8f6f4:
+ * out[m][n] = a_scale[m] w_scale[n] sum_k a8 w8.  a_codes / w_codes (uint8 [M,K] / [N,K], may be NULL) return the codes.
+ * M, N multiples of 16, K a multiple of 128. */
+VP_API int vp_dbg_fp8_gemm(int32_t device_id, int32_t M, int32_t N, int32_t K, const float* A, const float* a_scale, const float* W,
+                           const float* w_scale, float* out, uint8_t* a_codes, uint8_t* w_codes);
 /* calibration of the box: kind 0/1 = MFMA-only loop 16x16x32 / 32x32x16 f16 (TFLOP/s), 2 = float4 copy (TB/s) */
 VP_API int vp_dbg_peak(int32_t device_id, int32_t kind, double* result);
 

@@ -14,6 +14,9 @@ against the fp32 oracle, for the random checkpoint (noise-like maps, std 0.3) an
 prints heatmap rms / max error, confidence error and -- peaked maps -- coordinate error over all joints.
 
     python tests/fp8_budget.py [--crops 4] > profiles/fp8_study_r2.txt
+
+The operand quantisation used here (`q8_rows`) is confirmed on the hardware by tests/test_gpu_ops.py::test_fp8_probe_confirms_the_emulation
+(device codes == torch.float8_e4m3fn codes bit for bit; v_mfma_f32_16x16x128_f8f6f4 product == the emulation's product).
 """
 import argparse
 import os
@@ -28,11 +31,6 @@ from easy_vitpose_amd.configs import model_shape
 from easy_vitpose_amd.synth import synthetic_crops, synthetic_state_dict
 from oracle import vitpose_cpu as O
 
-ap = argparse.ArgumentParser()
-ap.add_argument('--crops', type=int, default=4)
-ap.add_argument('--variant', default='b')
-ap.add_argument('--dataset', default='ap10k')
-args = ap.parse_args()
 F8 = torch.float8_e4m3fn
 F8MAX = 448.0
 
@@ -97,27 +95,37 @@ def fwd(sd, x, depth, heads, mode, act_scales=None, record=None):
     return F.conv2d(x, sd['keypoint_head.final_layer.weight'], sd['keypoint_head.final_layer.bias'])
 
 
-torch.set_num_threads(16)
-with torch.no_grad():
-    shp = model_shape(args.variant, args.dataset)
-    crops = np.concatenate([synthetic_crops(args.crops // 2, 21, 'blobs'), synthetic_crops(args.crops - args.crops // 2, 22, 'noise')])
-    x = torch.from_numpy(np.concatenate([O.pre_img(c)[0] for c in crops]))
-    print(f'# ViTPose-{args.variant.upper()} / {args.dataset} (K = {shp.num_keypoints}), {args.crops} crops; errors against the fp32 oracle; tolerance: 1e-3 confidence, 0.5 px')
-    for peaked in (False, True):
-        sd = O.to_torch_state_dict(synthetic_state_dict(shp, 0, peaked=peaked))
-        ref = fwd(sd, x, shp.depth, shp.num_heads, 'fp32').numpy()
-        ref_kp = O.decode_per_crop(ref)
-        rec = {}
-        fwd(sd, x, shp.depth, shp.num_heads, 'fp16', record=rec)
-        print(f'\n== {"peaked" if peaked else "random"} checkpoint: heatmap std {ref.std():.3f}, confidences {ref_kp[..., 2].min():.2f} .. {ref_kp[..., 2].max():.2f}; '
-              f'max |A operand|: ' + ', '.join(f'{k} {v:.1f}' for k, v in rec.items()))
-        print(f'{"mode":8s} {"heatmap rms":>12s} {"heatmap max":>12s} {"conf max":>10s} {"conf rms":>10s} {"coord max px":>13s} {"joints > 1e-3":>14s} {"joints > 0.5px":>15s}')
-        for mode in ('fp16', 'w8', 'w8a8', 'w8a8t'):
-            hm = fwd(sd, x, shp.depth, shp.num_heads, mode, act_scales=rec).numpy()
-            kp = O.decode_per_crop(hm)
-            e = hm - ref
-            dc = np.abs(kp[..., 2] - ref_kp[..., 2])
-            dp = np.abs(kp[..., :2] - ref_kp[..., :2]).max(-1)
-            coord = f'{dp.max():13.3f}' if peaked else f'{"(noise maps)":>13s}'
-            print(f'{mode:8s} {np.sqrt((e ** 2).mean()):12.3e} {np.abs(e).max():12.3e} {dc.max():10.3e} {np.sqrt((dc ** 2).mean()):10.3e} {coord} '
-                  f'{int((dc > 1e-3).sum()):8d} / {dc.size:<4d} {(int((dp > 0.5).sum()) if peaked else 0):9d} / {dp.size:<4d}')
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--crops', type=int, default=4)
+    ap.add_argument('--variant', default='b')
+    ap.add_argument('--dataset', default='ap10k')
+    args = ap.parse_args()
+    torch.set_num_threads(16)
+    with torch.no_grad():
+        shp = model_shape(args.variant, args.dataset)
+        crops = np.concatenate([synthetic_crops(args.crops // 2, 21, 'blobs'), synthetic_crops(args.crops - args.crops // 2, 22, 'noise')])
+        x = torch.from_numpy(np.concatenate([O.pre_img(c)[0] for c in crops]))
+        print(f'# ViTPose-{args.variant.upper()} / {args.dataset} (K = {shp.num_keypoints}), {args.crops} crops; errors against the fp32 oracle; tolerance: 1e-3 confidence, 0.5 px')
+        for peaked in (False, True):
+            sd = O.to_torch_state_dict(synthetic_state_dict(shp, 0, peaked=peaked))
+            ref = fwd(sd, x, shp.depth, shp.num_heads, 'fp32').numpy()
+            ref_kp = O.decode_per_crop(ref)
+            rec = {}
+            fwd(sd, x, shp.depth, shp.num_heads, 'fp16', record=rec)
+            print(f'\n== {"peaked" if peaked else "random"} checkpoint: heatmap std {ref.std():.3f}, confidences {ref_kp[..., 2].min():.2f} .. {ref_kp[..., 2].max():.2f}; '
+                  f'max |A operand|: ' + ', '.join(f'{k} {v:.1f}' for k, v in rec.items()))
+            print(f'{"mode":8s} {"heatmap rms":>12s} {"heatmap max":>12s} {"conf max":>10s} {"conf rms":>10s} {"coord max px":>13s} {"joints > 1e-3":>14s} {"joints > 0.5px":>15s}')
+            for mode in ('fp16', 'w8', 'w8a8', 'w8a8t'):
+                hm = fwd(sd, x, shp.depth, shp.num_heads, mode, act_scales=rec).numpy()
+                kp = O.decode_per_crop(hm)
+                e = hm - ref
+                dc = np.abs(kp[..., 2] - ref_kp[..., 2])
+                dp = np.abs(kp[..., :2] - ref_kp[..., :2]).max(-1)
+                coord = f'{dp.max():13.3f}' if peaked else f'{"(noise maps)":>13s}'
+                print(f'{mode:8s} {np.sqrt((e ** 2).mean()):12.3e} {np.abs(e).max():12.3e} {dc.max():10.3e} {np.sqrt((dc ** 2).mean()):10.3e} {coord} '
+                      f'{int((dc > 1e-3).sum()):8d} / {dc.size:<4d} {(int((dp > 0.5).sum()) if peaked else 0):9d} / {dp.size:<4d}')
+
+
+if __name__ == '__main__':
+    main()

@@ -127,3 +127,57 @@ def test_deconv_bn_relu(dtype, B, Hin, Win, Cin):
                             torch.from_numpy(bn['weight']), torch.from_numpy(bn['bias']), training=False, eps=1e-5))
     err2 = np.abs(out - y.permute(0, 2, 3, 1).numpy()).max()
     assert err2 <= 4 * OUT_EPS[dtype] * np.abs(ref).max() + 1e-4, f'deconv vs module: {err2:.3e}'
+
+
+def test_fp8_probe_confirms_the_emulation():
+    """BASELINE config 5 (fp8 e4m3 weights on the fp8 MFMA) is documented tolerance-infeasible from a CPU emulation
+    (tests/fp8_budget.py).  This confirms the emulation on the hardware it stands for, on the real operands of
+    a ViTPose-B / AP-10K qkv GEMM (LayerNorm output of 2 crops x the checkpoint's attn.qkv.weight; per-token / per-output-channel
+    scales max|row| / 448 exactly as `fp8_budget.q8_rows`):
+      * the device's quantisation (x / scale, v_cvt_pk_fp8_f32) gives the codes of torch.float8_e4m3fn BIT FOR BIT;
+      * the product through v_mfma_f32_16x16x128_f8f6f4 equals the emulation's fp32 product of the de-quantised operands to fp32
+        accumulation rounding (the instruction adds exact e4m3 products; only the summation order differs);
+      * and the quantisation error of that one GEMM is what the study says: ~2-3 % of the output scale (fp16 operands: ~0.03 %)."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import fp8_budget as fb
+    from easy_vitpose_amd.configs import model_shape
+    from easy_vitpose_amd.synth import synthetic_crops, synthetic_state_dict
+    from oracle import vitpose_cpu as O
+    shp = model_shape('b', 'ap10k')
+    sd = O.to_torch_state_dict(synthetic_state_dict(shp, 0))
+    crops = synthetic_crops(2, 21, 'blobs')
+    x = torch.from_numpy(np.concatenate([O.pre_img(c)[0] for c in crops]))
+    with torch.no_grad():     # block 0's qkv operands: y = LN1(patch embed + pos), W = attn.qkv.weight
+        D = shp.embed_dim
+        t = F.conv2d(x, sd['backbone.patch_embed.proj.weight'], sd['backbone.patch_embed.proj.bias'], stride=16, padding=2)
+        t = t.view(2, D, 192).transpose(1, 2) + sd['backbone.pos_embed'][:, 1:] + sd['backbone.pos_embed'][:, :1]
+        y = F.layer_norm(t, (D,), sd['backbone.blocks.0.norm1.weight'], sd['backbone.blocks.0.norm1.bias'], eps=1e-6).reshape(-1, D).contiguous()
+        W = sd['backbone.blocks.0.attn.qkv.weight'].contiguous()
+        y[5, 17] = 1e5       # an extreme activation outlier: the row's other values land in e4m3's subnormal range (< 2^-6)
+        y[6] *= 1e-3
+        M, N, K = y.shape[0], W.shape[0], D
+        sa = (y.abs().amax(-1).clamp_min(1e-12) / fb.F8MAX).contiguous()
+        sw = (W.abs().amax(-1).clamp_min(1e-12) / fb.F8MAX).contiguous()
+        ca_ref = (y / sa[:, None]).to(fb.F8).view(torch.uint8).numpy()
+        cw_ref = (W / sw[:, None]).to(fb.F8).view(torch.uint8).numpy()
+        emu = F.linear(fb.q8_rows(y), fb.q8_rows(W)).numpy()                       # what fp8_budget.fwd computes for this GEMM
+        exact = (fb.q8_rows(y).double() @ fb.q8_rows(W).double().T).numpy()
+        full = (y.double() @ W.double().T).numpy()
+    out = np.empty((M, N), np.float32)
+    ca = np.empty((M, K), np.uint8)
+    cw = np.empty((N, K), np.uint8)
+    lib = capi.load_library()
+    yn, Wn, san, swn = (np.ascontiguousarray(a.numpy(), dtype=np.float32) for a in (y, W, sa, sw))
+    capi.check(lib.vp_dbg_fp8_gemm(0, M, N, K, _ptr(yn), _ptr(san), _ptr(Wn), _ptr(swn), _ptr(out), _ptr(ca), _ptr(cw)))
+    assert np.array_equal(ca, ca_ref), f'{(ca != ca_ref).sum()} activation codes differ from torch.float8_e4m3fn'
+    assert np.array_equal(cw, cw_ref), f'{(cw != cw_ref).sum()} weight codes differ from torch.float8_e4m3fn'
+    assert len(np.unique(ca)) > 100 and ((ca[5] & 0x78) == 0).mean() > 0.5     # the codes are exercised, subnormals included
+    scale = np.abs(fb.q8_rows(y).double().numpy()) @ np.abs(fb.q8_rows(W).double().numpy()).T
+    assert (np.abs(out - exact) / scale).max() < 5e-7                           # fp32 accumulation of exact products
+    assert (np.abs(out - emu) / scale).max() < 1e-6                             # == the emulation's GEMM
+    rel8 = np.sqrt(((out - full) ** 2).mean()) / full.std()
+    rel16 = np.sqrt((((round_to(yn, 'fp16').astype(np.float64) @ round_to(Wn, 'fp16').astype(np.float64).T) - full) ** 2).mean()) / full.std()
+    print(f'[fp8 probe] qkv GEMM {M}x{N}x{K}: e4m3 operand error {rel8:.3e} of the output scale, fp16 operands {rel16:.3e}')
+    assert 5e-3 < rel8 < 6e-2 and rel16 < 1e-3

@@ -279,6 +279,49 @@ def test_baseline_batch_properties():
     eng.close()
 
 
+def test_config5_ap10k_batch512_workload():
+    """BASELINE configs[4]'s WORKLOAD -- ViTPose-B / AP-10K (17 animal joints, configs/ViTPose_ap10k.py:4-22), batch 512 on one
+    GPU -- through the shipped fp16 path (its fp8 operands are tolerance-infeasible: DESIGN.md section 6, confirmed on the hardware by
+    test_fp8_probe_confirms_the_emulation).  Full-batch properties: finite, crop i of 512 == crop i alone, all 512 == the
+    small-batch path bit for bit; parity on 8 crops: heatmaps and confidences against the fp32 oracle on the bench's random
+    checkpoint, +-0.5 px / 1e-3 on every joint with the peaked checkpoint."""
+    from easy_vitpose_amd.configs import model_shape
+    from easy_vitpose_amd.synth import synthetic_state_dict
+    shp, sd, _ = weights('b', 'ap10k')
+    assert (shp.embed_dim, shp.depth, shp.num_heads, shp.num_keypoints) == (768, 12, 12, 17)
+    crops = synthetic_crops(512, 5, 'noise')
+    crops[:16] = synthetic_crops(16, 6, 'blobs')
+    eng = VitPoseHip(shp, sd, dtype='fp16', max_batch=512)
+    out = eng.infer(crops)
+    assert out.shape == (512, 17, 3) and np.isfinite(out).all()
+    assert np.array_equal(eng.infer(crops), out)                                        # run-to-run
+    idx = [0, 7, 255, 256, 300, 448, 510, 511]
+    assert np.array_equal(np.concatenate([eng.infer(crops[i:i + 1]) for i in idx]), out[idx])
+    hm = eng.heatmaps(crops[idx])
+    eng.close()
+    small = VitPoseHip(shp, sd, dtype='fp16', max_batch=16)
+    assert np.array_equal(small.infer(crops), out)                                      # 32 chunks of 16 crops, other kernels
+    small.close()
+    ref_hm = oracle_heatmaps('b', 'ap10k', crops[idx])
+    ref = O.decode_per_crop(ref_hm)
+    err = np.abs(hm - ref_hm)
+    cerr = np.abs(out[idx][..., 2] - ref[..., 2])
+    print(f'[b/ap10k @512] heatmap max err {err.max():.3e} rms {np.sqrt((err ** 2).mean()):.3e}; confidence max err {cerr.max():.3e} over {cerr.size} joints')
+    assert err.max() < HM_MAX_ERR['fp16'] and np.sqrt((err ** 2).mean()) < HM_RMS_ERR['fp16']
+    assert (cerr < CONF_TOL).mean() >= 0.95 and np.sqrt((cerr ** 2).mean()) < 0.5 * CONF_TOL     # noise-like maps: see test_large_variants_parity_vs_oracle
+    # coordinates on every joint: the peaked AP-10K checkpoint at the same batch size
+    psd = synthetic_state_dict(model_shape('b', 'ap10k'), 0, peaked=True)
+    peng = VitPoseHip(shp, psd, dtype='fp16', max_batch=512)
+    pout = peng.infer(crops)
+    peng.close()
+    psdt = O.to_torch_state_dict(psd)
+    pref = np.concatenate([O.inference_torch(psdt, shp.depth, shp.num_heads, crops[i]) for i in idx])
+    dpx = np.abs(pout[idx][..., :2] - pref[..., :2]).max(-1)
+    dcf = np.abs(pout[idx][..., 2] - pref[..., 2])
+    print(f'[b/ap10k @512, peaked] {dpx.size} joints: coordinate max err {dpx.max():.4f} px, confidence max err {dcf.max():.3e}')
+    assert dpx.max() < KP_TOL_PX and dcf.max() < CONF_TOL
+
+
 def test_persistent_gemm_is_bit_identical(monkeypatch):
     """qkv / fc1 run as persistent workgroups (operand ring carried across tile boundaries) once a launch has >= 1024
     tiles; the arithmetic per tile is unchanged, so keypoints must be bit-identical to the one-tile-per-workgroup

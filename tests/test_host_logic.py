@@ -136,10 +136,66 @@ def test_library_loads_and_exports_every_header_symbol():
     for name in declared:
         assert hasattr(lib, name), f'{name} declared in the header but not exported'
     assert sorted(capi.SYMBOLS) == declared, 'ctypes binding list and header disagree'
-    assert lib.vp_abi_version() == 2
+    assert lib.vp_abi_version() == 3
     # struct layout the header promises
     assert C.sizeof(capi.vp_config) == 28 and C.sizeof(capi.vp_tensor_desc) == 24
     assert C.sizeof(capi.vp_profile) == capi.VP_PROF_COUNT * 8 * 4
+
+
+def test_tools_library_exports_the_measurement_entry_points():
+    """include/vitpose_hip_tools.h = the -DVP_TOOLS build of the same sources (tools/ only): it exports everything the product
+    header declares plus the timeline taps; the PRODUCT library does not carry those."""
+    from easy_vitpose_amd.build import build_library, TOOLS_LIB
+    hdr = open(os.path.join(ROOT, 'include', 'vitpose_hip_tools.h')).read()
+    tools_only = sorted(set(re.findall(r'VP_API\s+[\w\s\*]+?\b(vp_\w+)\s*\(', hdr)))
+    assert tools_only == ['vp_dbg_gemm8_timeline', 'vp_dbg_gemm_timeline']
+    tl = C.CDLL(build_library(tools=True))
+    assert os.path.samefile(TOOLS_LIB, tl._name)
+    for name in tools_only + list(capi.SYMBOLS):
+        assert hasattr(tl, name), name
+    prod = capi.load_library()
+    for name in tools_only:
+        assert not hasattr(prod, name), f'{name} must not be in the product library'
+
+
+@pytest.mark.parametrize('n', [0, 1, 7, 64, 513])
+@pytest.mark.parametrize('w', [1, 2, 8])
+@pytest.mark.parametrize('maxb', [1, 8, 64])
+def test_group_sharding_plan(n, w, maxb):
+    """vp_group_infer's sharding (vitpose_api.hip group_plan, the function group_run executes) through the host-only tap
+    vp_dbg_group_plan: rounds of w * maxb crops, contiguous shards of ceil(nr / w) crops, no crop lost or duplicated, no shard
+    above max_batch, trailing devices short or empty -- for uneven tails, more devices than crops and multi-round calls.
+    No device needed: the multi-GPU path is checked before 8-GPU hardware shows up."""
+    lib = capi.load_library()
+    need = lib.vp_dbg_group_plan(n, w, maxb, None, None, 0)
+    rounds = -(-n // (w * maxb)) if n else 0
+    assert need == rounds * w
+    offs = (C.c_int32 * max(need, 1))()
+    cnts = (C.c_int32 * max(need, 1))()
+    assert lib.vp_dbg_group_plan(n, w, maxb, offs, cnts, need) == need
+    covered = []
+    for r in range(rounds):
+        nr = min(n - r * w * maxb, w * maxb)
+        per = -(-nr // w)
+        seen_short = False
+        for i in range(w):
+            off, cnt = offs[r * w + i], cnts[r * w + i]
+            assert 0 <= cnt <= min(per, maxb)
+            if cnt < per:
+                seen_short = True
+            else:
+                assert not seen_short                  # full shards first, then at most one short one, then empty ones
+            if cnt:
+                covered.extend(range(off, off + cnt))
+                assert off == r * w * maxb + i * per   # the same bounds the one-process-per-GPU host uses
+    assert covered == list(range(n))
+    # agreement with easy_vitpose_amd.parallel.shard_bounds (RCCL host) inside one round
+    from easy_vitpose_amd.parallel import shard_bounds
+    if rounds == 1:
+        for i in range(w):
+            lo, hi = shard_bounds(n, w, i)
+            assert (offs[i], cnts[i]) == (min(lo, n), hi - lo) or (cnts[i] == 0 and hi == lo)
+    assert lib.vp_dbg_group_plan(-1, w, maxb, None, None, 0) < 0 and lib.vp_dbg_group_plan(n, 0, maxb, None, None, 0) < 0
 
 
 def test_bad_config_is_rejected_before_touching_a_device():

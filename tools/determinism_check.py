@@ -7,6 +7,8 @@ import sys
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import _toolslib  # noqa: F401,E402  (measurement build of the library)
 from easy_vitpose_amd.configs import model_shape
 from easy_vitpose_amd.engine import VitPoseHip
 from easy_vitpose_amd.synth import synthetic_crops, synthetic_state_dict

@@ -4,6 +4,8 @@ operand DMA after the prologue, 8 = no epilogue stores) x diagnosis BUILDS of ge
 2 = no main-loop barriers, 4 = no MFMAs; results are garbage, timing is the point).   VP_HIP_LIB=<build> python tools/gemm8_ablate2.py"""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import _toolslib  # noqa: F401,E402  (measurement build of the library)
 from easy_vitpose_amd import _capi as capi
 lib = capi.load_library()
 M = 49152

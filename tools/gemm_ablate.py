@@ -3,6 +3,8 @@
 8 = no epilogue stores.  Shows how much of a launch is operand delivery / epilogue / the bare MFMA loop."""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import _toolslib  # noqa: F401,E402  (measurement build of the library)
 from easy_vitpose_amd import _capi as capi
 lib = capi.load_library()
 M = 49152

@@ -9,6 +9,8 @@ import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import _toolslib  # noqa: F401,E402  (measurement build of the library)
 from easy_vitpose_amd import _capi as capi
 from easy_vitpose_amd.configs import VARIANTS
 

@@ -3,6 +3,8 @@
 (elementwise.hip issue_probe_kernel), with one and with two waves per SIMD.  Output: ns per round of 16 MFMAs."""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import _toolslib  # noqa: F401,E402  (measurement build of the library)
 from easy_vitpose_amd import _capi as capi
 lib = capi.load_library()
 names = {0: 'MFMA only', 1: '+1 store', 2: '+1 DMA', 3: '+1 store +1 DMA', 4: '+48 VALU', 5: '+1 store +48 VALU', 6: '+1 DMA +48 VALU',

@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import _toolslib  # noqa: F401,E402  (measurement build of the library)
 from easy_vitpose_amd import _capi as capi
 lib = capi.load_library()
 for kind, name in [(0, 'MFMA f16 16x16x32 only (TFLOP/s)'), (1, 'MFMA f16 32x32x16 only (TFLOP/s)'), (2, 'float4 copy read+write (TB/s)'),

@@ -7,6 +7,8 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import _toolslib  # noqa: F401,E402  (measurement build of the library)
 
 if len(sys.argv) > 1 and sys.argv[1] == 'child':
     import hashlib
