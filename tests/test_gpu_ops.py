@@ -129,6 +129,14 @@ def test_deconv_bn_relu(dtype, B, Hin, Win, Cin):
     assert err2 <= 4 * OUT_EPS[dtype] * np.abs(ref).max() + 1e-4, f'deconv vs module: {err2:.3e}'
 
 
+# v_mfma_f32_16x16x128_f8f6f4 does NOT add its products as an fp32 fmaf chain: measured on MI355X (tools/fp8_probe_rows.py,
+# profiles/fp8_probe_r3.txt) the result deviates from the exact sum of the same e4m3 products by up to ~2-3e-4 of the LARGEST product of
+# the instruction (median 2-4e-5), and is exact when all products have one magnitude -- the products are aligned to the largest one and
+# the smaller ones lose their low bits.  Relative to sum |a||w| of a K = 768 row that is <= 6e-6 for ordinary rows and 1.6e-4 for a row
+# with one dominant product (an activation outlier): one more reason the fp8 configuration cannot meet a 1e-3 confidence tolerance.
+FP8_ACC_TOL = 2e-5
+
+
 def test_fp8_probe_confirms_the_emulation():
     """BASELINE config 5 (fp8 e4m3 weights on the fp8 MFMA) is documented tolerance-infeasible from a CPU emulation
     (tests/fp8_budget.py).  This confirms the emulation on the hardware it stands for, on the real operands of
@@ -175,9 +183,16 @@ def test_fp8_probe_confirms_the_emulation():
     assert np.array_equal(cw, cw_ref), f'{(cw != cw_ref).sum()} weight codes differ from torch.float8_e4m3fn'
     assert len(np.unique(ca)) > 100 and ((ca[5] & 0x78) == 0).mean() > 0.5     # the codes are exercised, subnormals included
     scale = np.abs(fb.q8_rows(y).double().numpy()) @ np.abs(fb.q8_rows(W).double().numpy()).T
-    assert (np.abs(out - exact) / scale).max() < 5e-7                           # fp32 accumulation of exact products
-    assert (np.abs(out - emu) / scale).max() < 1e-6                             # == the emulation's GEMM
-    rel8 = np.sqrt(((out - full) ** 2).mean()) / full.std()
-    rel16 = np.sqrt((((round_to(yn, 'fp16').astype(np.float64) @ round_to(Wn, 'fp16').astype(np.float64).T) - full) ** 2).mean()) / full.std()
+    rel = np.abs(out - exact) / scale
+    rel_emu = np.abs(out - emu) / scale
+    normal = np.ones(M, bool)
+    normal[5] = False
+    print(f'[fp8 probe] product vs fp64 of the same codes, relative to sum|a||w|: ordinary rows max {rel[normal].max():.3e}, '
+          f'outlier row (one 448 among subnormals) max {rel[5].max():.3e}; vs the emulation {rel_emu[normal].max():.3e} / {rel_emu[5].max():.3e}')
+    assert rel[normal].max() < FP8_ACC_TOL and rel_emu[normal].max() < FP8_ACC_TOL   # == the emulation's GEMM on ordinary rows
+    assert rel[5].max() < 1e-3                                                  # the outlier row: see FP8_ACC_TOL
+    # the quantisation error of this one GEMM (ordinary rows: the 1e5 outlier of row 5 is outside fp16's range)
+    rel8 = np.sqrt(((out - full)[normal] ** 2).mean()) / full[normal].std()
+    rel16 = np.sqrt((((round_to(yn[normal], 'fp16').astype(np.float64) @ round_to(Wn, 'fp16').astype(np.float64).T) - full[normal]) ** 2).mean()) / full[normal].std()
     print(f'[fp8 probe] qkv GEMM {M}x{N}x{K}: e4m3 operand error {rel8:.3e} of the output scale, fp16 operands {rel16:.3e}')
     assert 5e-3 < rel8 < 6e-2 and rel16 < 1e-3
