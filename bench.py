@@ -287,6 +287,11 @@ def host_path_rate(eng, crops_u8, K, seconds=1.5):
 
 
 def main():
+    # The ONE JSON line must be the only thing on stdout: RCCL prints a version banner to the C-level stdout of rank 0 (buffered, so it
+    # lands AFTER python's own output at exit).  fd 1 is pointed at stderr for the whole run and the line goes to the saved descriptor.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=100)
@@ -438,7 +443,7 @@ def main():
         else:
             line['cpu_baseline'] = None
             line['cpu_baseline_batched'] = None
-        print(json.dumps(line), flush=True)
+        os.write(json_fd, (json.dumps(line) + '\n').encode())
     eng.close()
     if use_dist:
         dist.destroy_process_group()

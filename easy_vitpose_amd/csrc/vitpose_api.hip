@@ -122,6 +122,7 @@ struct vp_ctx {
     int gemm_variant[VP_PROF_COUNT] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1};   // tile cfg per GEMM family, -1 = default rule
     int gemm_group_m[VP_PROF_COUNT] = {0};
     int gemm_ablate = 0;   // profiling only
+    int fam_ablate[VP_PROF_COUNT] = {0};   // VP_TOOLS: per-family ablation / experiment bits in the forward pass (VP_ABLATE_FAM="fam:bits,...")
     struct Ev { hipEvent_t a, b; int fam; double flops, bytes; };
     std::vector<Ev> evs;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
@@ -368,7 +369,7 @@ int gemm(vp_ctx* c, int fam, int epi, const uint16_t* A, const uint16_t* W, cons
     g.w_rows = (int)pad128((size_t)N);
     g.variant = c->gemm_variant[fam];
     g.group_m = c->gemm_group_m[fam];
-    g.ablate = c->gemm_ablate;
+    g.ablate = c->gemm_ablate | c->fam_ablate[fam];
     if (g.variant < 0) {
         // default: the 192(m) x 128(n) tile -- M is always a multiple of 192 tokens (one crop per m-tile), so
         // the tile count divides evenly over 256 CUs x 2 blocks at the BASELINE batch; best or tied for every
@@ -661,6 +662,14 @@ int vp_create(vp_handle* out, const vp_config* cfg) {
     if (const char* f = getenv("VP_G8_STAGGER")) c->g8_stagger = atoi(f);
     if (const char* f = getenv("VP_FOLD_STATS")) c->graph_max_n_stats = atoi(f) != 0 ? 16 : 0;
     if (const char* f = getenv("VP_G8_DEFERRED")) c->g8_deferred = atoi(f) != 0;
+    if (const char* t = getenv("VP_ABLATE_FAM")) {   // e.g. "2:64,1:64" = non-temporal stores in the qkv and fc1 epilogues
+        int f, b, used = 0;
+        while (sscanf(t, "%d:%d%n", &f, &b, &used) == 2) {
+            if (f >= 0 && f < VP_PROF_COUNT) c->fam_ablate[f] = b;
+            t += used;
+            if (*t == ',') ++t; else break;
+        }
+    }
 #endif
     if (c->fuse_ln) {
         if ((rc = dalloc(c, &c->ln_part, M * (size_t)(D / 64) * 2))) return bail(rc);

@@ -16,7 +16,8 @@ pmc_json = {}
 
 
 def short(name):
-    name = re.sub(r'\(.*$', '', name.replace('void ', '').replace('vp::', ''))
+    name = name.replace('void ', '').replace('(anonymous namespace)::', '').replace('vp::', '')
+    name = re.sub(r'\(.*$', '', name).replace(' >', '>')
     return name[:100]
 
 
