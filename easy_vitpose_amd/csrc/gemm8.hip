@@ -8,24 +8,25 @@
 //    Every wave owns a 128(m) x BN/4(n) output block made of 64 rows from EACH X half and BN/8 (BN = 256) rows from each W
 //    half, so its accumulators split into four quadrants q(hm, hn) = X-half hm x W-half hn, and a quadrant needs exactly
 //    one X slot and one W slot.
-//  * 4 phases per K-tile, 8 per loop iteration (two K-tiles, compile-time buffer index and fragment-set roles):
-//        P1: read X0 fragments (8 ds_read_b128)            | DMA W0(t+2) | lgkmcnt(0) | barrier | MFMA q00 | barrier
-//        P2: read W1 fragments (4)                         | DMA X0(t+2) | lgkmcnt(0) | barrier | MFMA q01 | barrier
-//        P3: read X1 fragments (8)                         | DMA W1(t+2) | vmcnt | lgkmcnt(0) | barrier | MFMA q11 | barrier
-//        P4: read W0 fragments of K-tile t+1 (4, other buffer, into the set W1 just left) | DMA X1(t+2) | lgkmcnt(0) | barrier | MFMA q10 | barrier
-//    One slot is restaged per phase (global_load_lds, 16 B per lane); the only vmcnt wait of a K-tile sits in P3 and is
-//    COUNTED (the three youngest slots stay in flight across it), so HBM/L2 latency is covered by 3 phases of MFMAs.
-//    The first K-tile of a tile reads its W0 in P1 (nothing is live across the epilogue) and restages W0 in P2 instead.
-//  * two wave groups (waves 0-3 / 4-7 = the two waves of every SIMD) run the same stream ONE BARRIER APART: while
-//    one wave of a SIMD streams its 16 MFMAs, its SIMD partner reads fragments and issues the DMA of its phase.
+//  * 2 segments per K-tile (round 3; round 2 ran four phases of one quadrant each -- same speed to 1 %, 8 barriers and 4 load sections
+//    per K-tile, 15-25 registers more, a first-K-tile special case; profiles/gemm8_sched_r3.txt):
+//        LA: read X0, W0, W1 fragments (16 / 14 ds_read_b128) | DMA X1 <- K-tile t+1 (other buffer) | counted vmcnt | lgkmcnt(0) | barrier
+//        MA: MFMA q00, q01 (32 / 24)                                                                                              | barrier
+//        LB: read X1 fragments (8)      | DMA X0, W0, W1 <- K-tile t+2 (this buffer)                | counted vmcnt | lgkmcnt(0) | barrier
+//        MB: MFMA q10, q11 (32 / 24)                                                                                              | barrier
+//    Slots are restaged by global_load_lds (16 B per lane); every load section ends with ONE counted wait that leaves exactly the
+//    pieces issued since the previous section's wait in flight (6 + NW1), so a slot has 1 - 1.5 K-tiles of MFMAs to land.
+//  * two wave groups (waves 0-3 / 4-7 = the two waves of every SIMD) run the same stream ONE BARRIER APART: while one wave of a
+//    SIMD streams its MFMAs, its SIMD partner reads fragments and issues the DMA of its segment.
 //  * ordering rules the schedule is built on (MI355X_MICROARCH.md, "Two waves per SIMD", item 7):
-//      RAW: a slot is read one phase AFTER the phase whose vmcnt retired it (P3(t) retires K-tile t+1, first read in P4(t));
-//      WAR: every LOAD section ends with lgkmcnt(0) BEFORE the phase's first barrier, so a slot may be restaged in the
-//           next phase: X0 P1 -> P2, W1 P2 -> P3, X1 P3 -> P4, W0(t+1) P4(t) -> P1(t+1).
-//    (Round 2 history: the first version read W0 + X0 in P1 and nothing in P4 (12 / 4 / 8 / 0 reads) with the wait in P4; this
-//    one measures 1.2 % faster end to end on the same box.  profiles/gemm8_sections_r2.txt has the section timings and the
-//    variants that were measured and not shipped: one barrier per phase, W reads inside the MFMA sections, 6/6/6/6 reads,
-//    32x32x16 MFMAs.)
+//      WAR: X0 / W0 / W1 of buffer B are read in LA(t) by group 0 and one segment later by group 1; both are past them at the barrier
+//           in front of group 0's LB(t), where their restage starts (group 1 restages in ITS LB(t), later still).  X1 of buffer B is
+//           read in LB(t) / one segment later and restaged in LA(t+1), behind the barrier that ends group 1's LB(t).  Every load
+//           section ends with lgkmcnt(0) before its barrier.
+//      RAW: LA(t) retires X1(t) (issued in LA(t-1), read in LB(t)); LB(t) retires X0 / W0 / W1 of K-tile t+1 (issued in LB(t-1), read
+//           in LA(t+1)): the reading section starts two barriers after group 0's wait and one after group 1's.
+//      tile boundary: the last LB of a tile waits one group deeper (it also retires X1 of the next tile's first K-tile), so the first
+//           LA of a tile needs no wait -- a counted wait right behind the epilogue would wait for the epilogue's stores.
 //  * the LDS image of a slot is lane-linear (global_load_lds writes wave base + lane * 16): the XOR swizzle of the
 //    16-byte k-slots is applied to the per-lane SOURCE address and again on the ds_read_b128 fragment reads.
 //  * persistent workgroups: the ring runs on across tile boundaries (the next tile's first two K-tiles stream in during
@@ -119,7 +120,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs g) {
     const int w1off = wc * 16 * C::NF1 * 128 + foff;  // W half 1
 
     f32x4 acc[C::TI][8];
-    // fragment registers.  W: two sets that swap roles every K-tile (W0 of K-tile t <-> W1 of t, then W0 of t+1)
+    // fragment registers: the current X half (both k-halves), W0, W1
     u32x4 xs[4][2], fa[2][2], fb[2][2];
 
     auto zero_acc = [&]() {
@@ -129,147 +130,112 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs g) {
             for (int j = 0; j < 8; ++j) acc[f][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     };
 
-    // one K-tile t: ring buffer B holds it; kn2 = K-tile index (relative to the ISSUE tile pointers) of the K-tile two ahead, whose
-    // four slots are restaged here, one per phase; sw = switch the issue pointers to the next tile first.
-    // MODE 1 = first K-tile of a tile (W0 and all of X0 are read here; the W0 restage moves to P2),
-    // MODE 2 = last K-tile of a tile (no read-ahead of the next K-tile: no fragment is live across the epilogue).
-    unsigned long long ks[4] = {0, 0, 0, 0};   // tools/gemm8_timeline.py (ablate 32): P3 wait of K-tiles 0 and 1 of a tile, begin / end
 #ifndef VP_G8_ABL
-#define VP_G8_ABL 0   // diagnosis builds (tools/gemm8_ablate2.py, tools/gemm8_timeline.py): 1 = no fragment reads after a tile's first K-tile,
-                      // 2 = no barriers in the main loop, 4 = no MFMAs, 16 = cycle stamps around every section of one K-tile
+#define VP_G8_ABL 0   // diagnosis builds (tools/gemm8_ablate2.py): 1 = no fragment reads after a tile's first K-tile, 2 = no barriers in the
+                      // main loop, 4 = no MFMAs
 #endif
 #define KBAR() do { if (!(VP_G8_ABL & 2)) bar(); } while (0)
-#if (VP_G8_ABL & 16)
-    unsigned long long sec[24];
+#if (VP_G8_ABL & 16)   // cycle stamps around every section of ONE K-tile (K-tile 4 of each workgroup's second tile): tools/gemm8_timeline.py
+    unsigned long long sec[12];
 #pragma unroll
-    for (int i = 0; i < 24; ++i) sec[i] = 0;
-#define SEC(i) do { if (stamp == 2) sec[i] = __builtin_readcyclecounter(); } while (0)
+    for (int i = 0; i < 12; ++i) sec[i] = 0;
+    bool stamp_now = false;
+#define SEC(i) do { if (stamp_now) sec[i] = __builtin_readcyclecounter(); } while (0)
 #else
 #define SEC(i) do { } while (0)
 #endif
-    auto ktile = [&](auto Bc, auto Mc, int kn2, bool sw, int nm0, int nn0, int stamp = -1) {
+    // one K-tile t in ring buffer B (two segments, see the top of the file): kA / kB = K-tile indices (relative to the ISSUE tile
+    // pointers) of the K-tiles whose X1 / X0, W0, W1 are restaged here; swB = switch the issue pointers to the next tile before LB's
+    // restage.  MODE 1 = first K-tile of a tile (no wait in LA), 2 = last K-tile of a tile (deeper wait in LB).
+    constexpr int NKEEP = 6 + C::NW1;   // pieces of one LA (2) + one LB (4 + NW1) issue: what a counted wait leaves in flight
+    auto ktile = [&](auto Bc, auto Mc, int kA, int kB, bool swB, int nm0, int nn0) {
         constexpr int B = decltype(Bc)::value;
         constexpr int MODE = decltype(Mc)::value;
         const char* sb = smem + B * C::BUF;
-        const char* sn = smem + (B ^ 1) * C::BUF;
-        u32x4(&w0)[2][2] = (B == 0) ? fa : fb;   // W0 of this K-tile
-        u32x4(&w1)[2][2] = (B == 0) ? fb : fa;   // W1 of this K-tile, then (P4) W0 of the next one
-        if (sw) set_tile(nm0, nn0);
         SEC(0);
-        // ---------------- P1: X0 | DMA W0(t+2)
-        if constexpr (MODE == 1) {
+        // ---------------- LA: X0, W0, W1 | DMA X1(t+1)
 #pragma unroll
-            for (int p = 0; p < 2; ++p)
+        for (int p = 0; p < 2; ++p)
 #pragma unroll
-                for (int kk = 0; kk < 2; ++kk) w0[p][kk] = *(const u32x4*)(sb + C::OFF_W0 + ((w0off + p * 2048) ^ (kk << 6)));
-            __builtin_amdgcn_sched_barrier(0);
-        }
+            for (int kk = 0; kk < 2; ++kk) if (MODE == 1 || !(VP_G8_ABL & 1)) fa[p][kk] = *(const u32x4*)(sb + C::OFF_W0 + ((w0off + p * 2048) ^ (kk << 6)));
+#pragma unroll
+        for (int p = 0; p < C::NF1; ++p)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) if (MODE == 1 || !(VP_G8_ABL & 1)) fb[p][kk] = *(const u32x4*)(sb + C::OFF_W1 + ((w1off + p * 2048) ^ (kk << 6)));
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) if (MODE == 1 || !(VP_G8_ABL & 1)) xs[j][kk] = *(const u32x4*)(sb + C::OFF_X0 + ((xoff + j * 2048) ^ (kk << 6)));
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (MODE != 1) issue(2, B, kn2);
-        wait_lgkm<0>();   // every read of this phase has returned before the barrier: its slot may be restaged one phase later
         SEC(1);
-        KBAR();
+        issue(1, B ^ 1, kA);
         SEC(2);
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-            for (int p = 0; p < 2; ++p)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) if (!(VP_G8_ABL & 4)) acc[p][j] = mfma16<T>(w0[p][kk], xs[j][kk], acc[p][j]);
-        __builtin_amdgcn_s_setprio(0);
+        if constexpr (MODE != 1) wait_vm<NKEEP>();
+        wait_lgkm<0>();
         SEC(3);
         KBAR();
         SEC(4);
-        // ---------------- P2: W1 | DMA X0(t+2)
-#pragma unroll
-        for (int p = 0; p < C::NF1; ++p)
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) if (!(VP_G8_ABL & 1)) w1[p][kk] = *(const u32x4*)(sb + C::OFF_W1 + ((w1off + p * 2048) ^ (kk << 6)));
-        __builtin_amdgcn_sched_barrier(0);
-        if constexpr (MODE == 1) issue(2, B, kn2);
-        issue(0, B, kn2);
-        wait_lgkm<0>();
-        SEC(5);
-        KBAR();
-        SEC(6);
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
+        for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+            for (int p = 0; p < 2; ++p)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) if (!(VP_G8_ABL & 4)) acc[p][j] = mfma16<T>(fa[p][kk], xs[j][kk], acc[p][j]);
 #pragma unroll
             for (int p = 0; p < C::NF1; ++p)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) if (!(VP_G8_ABL & 4)) acc[2 + p][j] = mfma16<T>(w1[p][kk], xs[j][kk], acc[2 + p][j]);
+                for (int j = 0; j < 4; ++j) if (!(VP_G8_ABL & 4)) acc[2 + p][j] = mfma16<T>(fb[p][kk], xs[j][kk], acc[2 + p][j]);
+        }
         __builtin_amdgcn_s_setprio(0);
-        SEC(7);
+        SEC(5);
         KBAR();
-        SEC(8);
-        // ---------------- P3: X1 | DMA W1(t+2) | counted wait: K-tile t+1 complete
+        SEC(6);
+        // ---------------- LB: X1 | DMA X0, W0, W1 (t+2)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) if (!(VP_G8_ABL & 1)) xs[j][kk] = *(const u32x4*)(sb + C::OFF_X1 + ((xoff + j * 2048) ^ (kk << 6)));
         __builtin_amdgcn_sched_barrier(0);
-        issue(3, B, kn2);
-        if (stamp >= 0) ks[2 * stamp] = __builtin_readcyclecounter();
-        wait_vm<C::INFLIGHT>();   // everything up to P4(t-1)'s DMA has landed (own share): K-tile t+1 is complete
-        if (stamp >= 0) ks[2 * stamp + 1] = __builtin_readcyclecounter();
+        if (swB) set_tile(nm0, nn0);
+        issue(2, B, kB);
+        issue(0, B, kB);
+        issue(3, B, kB);
+        SEC(7);
+        if constexpr (MODE == 2) wait_vm<C::INFLIGHT>(); else wait_vm<NKEEP>();
         wait_lgkm<0>();
-        SEC(9);
+        SEC(8);
         KBAR();
-        SEC(10);
+        SEC(9);
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
+        for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+            for (int p = 0; p < 2; ++p)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) if (!(VP_G8_ABL & 4)) acc[p][4 + j] = mfma16<T>(fa[p][kk], xs[j][kk], acc[p][4 + j]);
 #pragma unroll
             for (int p = 0; p < C::NF1; ++p)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) if (!(VP_G8_ABL & 4)) acc[2 + p][4 + j] = mfma16<T>(w1[p][kk], xs[j][kk], acc[2 + p][4 + j]);
-        __builtin_amdgcn_s_setprio(0);
-        SEC(11);
-        KBAR();
-        SEC(12);
-        // ---------------- P4: W0 of K-tile t+1 (from the other buffer, into the fragment set W1 just left) | DMA X1(t+2)
-        if constexpr (MODE != 2) {
-#pragma unroll
-            for (int p = 0; p < 2; ++p)
-#pragma unroll
-                for (int kk = 0; kk < 2; ++kk) if (!(VP_G8_ABL & 1)) w1[p][kk] = *(const u32x4*)(sn + C::OFF_W0 + ((w0off + p * 2048) ^ (kk << 6)));
-            __builtin_amdgcn_sched_barrier(0);
+                for (int j = 0; j < 4; ++j) if (!(VP_G8_ABL & 4)) acc[2 + p][4 + j] = mfma16<T>(fb[p][kk], xs[j][kk], acc[2 + p][4 + j]);
         }
-        issue(1, B, kn2);
-        wait_lgkm<0>();
-        SEC(13);
-        KBAR();
-        SEC(14);
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-            for (int p = 0; p < 2; ++p)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) if (!(VP_G8_ABL & 4)) acc[p][4 + j] = mfma16<T>(w0[p][kk], xs[j][kk], acc[p][4 + j]);
         __builtin_amdgcn_s_setprio(0);
-        SEC(15);
+        SEC(10);
         KBAR();
-        SEC(16);
+        SEC(11);
     };
-#undef SEC
 #undef KBAR
+#undef SEC
     using M0 = std::integral_constant<int, 0>;
     using M1 = std::integral_constant<int, 1>;
     using M2 = std::integral_constant<int, 2>;
     using B0 = std::integral_constant<int, 0>;
     using B1 = std::integral_constant<int, 1>;
-    // (re)start of the ring on the issue tile: K-tiles 0 and 1 completely issued, K-tile 0 landed and visible
+    // (re)start of the ring on the issue tile: K-tile 0 and X0 / W0 / W1 of K-tile 1 issued, K-tile 0 landed and visible
     auto ring_start = [&]() {
         issue(2, 0, 0, true); issue(0, 0, 0, true); issue(3, 0, 0, true); issue(1, 0, 0, true);
-        issue(2, 1, 1, true); issue(0, 1, 1, true); issue(3, 1, 1, true); issue(1, 1, 1, true);
-        wait_vm<C::INFLIGHT + 2>();   // the eight DMA pieces of K-tile 1 stay in flight
+        issue(2, 1, 1, true); issue(0, 1, 1, true); issue(3, 1, 1, true);   // X1 of K-tile 1 is issued by the first LA
+        wait_vm<C::INFLIGHT>();       // K-tile 0 landed; X0 / W0 / W1 of K-tile 1 stay in flight
         bar();
         if (wr) bar();   // stagger: waves 4-7 run one barrier behind waves 0-3
     };
@@ -294,15 +260,21 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs g) {
         const bool tl = (VP_ABLATE(g) & 32) != 0;
         unsigned long long ts0 = 0, ts1 = 0;
         if (tl) ts0 = __builtin_readcyclecounter();
-        ktile(B0{}, M1{}, 2, false, 0, 0, tl ? 0 : -1);
-        ktile(B1{}, M0{}, 3, false, 0, 0, tl ? 1 : -1);
+        ktile(B0{}, M1{}, 1, 2, false, 0, 0);
+        ktile(B1{}, M0{}, 2, 3, false, 0, 0);
         for (int kt = 2; kt < nk - 2; kt += 2) {
-            ktile(B0{}, M0{}, kt + 2, false, 0, 0, (tl && kt == 4) ? 2 : -1);
-            ktile(B1{}, M0{}, kt + 3, false, 0, 0);
+#if (VP_G8_ABL & 16)
+            stamp_now = tl && kt == 4 && (t - tw.j0) / tw.nloc == 1;
+#endif
+            ktile(B0{}, M0{}, kt + 1, kt + 2, false, 0, 0);
+#if (VP_G8_ABL & 16)
+            stamp_now = false;
+#endif
+            ktile(B1{}, M0{}, kt + 2, kt + 3, false, 0, 0);
         }
-        // last two K-tiles: everything they restage belongs to the next tile
-        ktile(B0{}, M0{}, 0, true, nm0, nn0);
-        ktile(B1{}, M2{}, 1, false, 0, 0);
+        // last two K-tiles: LA(nk-2) still restages this tile's last X1; from LB(nk-2) on everything belongs to the next tile
+        ktile(B0{}, M0{}, nk - 1, 0, true, nm0, nn0);
+        ktile(B1{}, M2{}, 0, 1, false, 0, 0);
         if (tl) ts1 = __builtin_readcyclecounter();
 
         // ---------------- epilogue of tile (m0, n0) ----------------
@@ -459,13 +431,12 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs g) {
                 const int ti = (t - tw.j0) / tw.nloc;
                 if (ti < 16) {
                     unsigned long long* sp = (unsigned long long*)g.stats_out + (((size_t)blockIdx.x * 2 + wr) * 16 + ti) * 8;
-                    sp[0] = ts0; sp[1] = ts1; sp[2] = __builtin_readcyclecounter();
-                    sp[3] = ks[0]; sp[4] = ks[1]; sp[5] = ks[2]; sp[6] = ks[3];
+                    sp[0] = ts0; sp[1] = ts1; sp[2] = __builtin_readcyclecounter();   // main loop begin / end, epilogue end
 #if (VP_G8_ABL & 16)
                     if (ti == 1) {
                         unsigned long long* sq = (unsigned long long*)g.stats_out + (((size_t)blockIdx.x * 2 + wr) * 16 + 8) * 8;
 #pragma unroll
-                        for (int i = 0; i < 24; ++i) sq[i] = sec[i];
+                        for (int i = 0; i < 12; ++i) sq[i] = sec[i];
                     }
 #endif
                 }

@@ -48,26 +48,20 @@ for name, epi, N, flags in (('qkv', 0, 3 * D, 16), ('fc1', 1, 4 * D, 16 | 2)):
     t0 = s[:, :, :ntile, :]
     loop = t0[..., 1] - t0[..., 0]
     epi_t = t0[..., 2] - t0[..., 1]
-    w0 = t0[..., 4] - t0[..., 3]
-    w1 = t0[..., 6] - t0[..., 5]
     start = t0[:, 0, 0, 0].min()
     print(f'{name}: {ntile} tiles per workgroup (stamps of wave 0 / wave 4, medians over 256 workgroups, shader cycles)')
     for grp in (0, 1):
         print(f'  group {grp}: main loop {np.median(loop[:, grp], 0).astype(int).tolist()}')
         print(f'           epilogue  {np.median(epi_t[:, grp], 0).astype(int).tolist()}')
-        print(f'           P4 wait of K-tile 0 {np.median(w0[:, grp], 0).astype(int).tolist()}')
-        print(f'           P4 wait of K-tile 1 {np.median(w1[:, grp], 0).astype(int).tolist()}')
     gap = t0[:, 0, 1:, 0] - t0[:, 0, :-1, 2]
     print(f'  gap epilogue end -> next loop begin {np.median(gap, 0).astype(int).tolist()}')
     tot = t0[:, 0, ntile - 1, 2].max() - start
     print(f'  launch span {tot} cycles; epilogue-begin spread per tile (max - min over workgroups): {(t0[:, 0, :, 1].max(0) - t0[:, 0, :, 1].min(0)).tolist()}')
-    sec = s[:, :, 8:11, :].reshape(256, 2, 24)
+    sec = s[:, :, 8:10, :].reshape(256, 2, 16)[:, :, :12]
     if (sec[:, 0, 1] > 0).any():   # diagnosis build (-DVP_G8_ABL=16): section stamps of K-tile 4 of each workgroup's second tile
-        names = []
-        for ph in range(1, 5):
-            names += [f'P{ph} load->lgkm', f'P{ph} bar', f'P{ph} mfma issue', f'P{ph} bar2']
+        names = ['LA reads', 'LA dma X1', 'LA waits', 'bar', 'MA mfma', 'bar', 'LB reads + dma X0 W0 W1', 'LB waits', 'bar', 'MB mfma', 'bar']
         for grp in (0, 1):
-            d = np.diff(sec[:, grp, :17], axis=1)
+            d = np.diff(sec[:, grp, :], axis=1)
             ok = (sec[:, grp, 1] > 0)
             med = np.median(d[ok], 0).astype(int)
             print(f'  group {grp} sections of one K-tile (median cycles): ' + ', '.join(f'{n}={v}' for n, v in zip(names, med)) + f'  total {int(med.sum())}')
