@@ -48,6 +48,7 @@
 #define VP_G8_RESD 1
 #endif
 
+
 namespace vp {
 
 // EPI: EPI_BIAS / EPI_BIAS_GELU (16-bit output straight from registers, optional LayerNorm-consumer fold, optional
