@@ -135,4 +135,18 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
     return base + idx;
 }
 
+// GELU (exact erf form, vit.py:127 nn.GELU) = max(x, 0) - |x| / 2 * erfc(|x| / sqrt 2), with erfc(t / sqrt 2) = 2^(-t P(t)), P a degree-4
+// minimax fit of -log2(erfc(t / sqrt 2)) / t: one transcendental + 9 VALU instructions, |error| <= 1.2e-6 in fp32 (far below the 16-bit
+// rounding of the result).  The factor 1/2 rides in the exponent (2^(-t P - 1)): one multiplication less than the round-2 form.
+// ONE definition for every GEMM kernel: the fc1 configurations must agree bit for bit.
+__device__ __forceinline__ float gelu_erf(float x) {
+    const float a = fabsf(x);
+    float q = fmaf(a, 5.204574411e-04f, -7.397505390e-03f);
+    q = fmaf(q, a, 5.256122897e-02f);
+    q = fmaf(q, a, 4.592546873e-01f);
+    q = fmaf(q, a, 1.151091354e+00f);
+    const float h = __builtin_amdgcn_exp2f(fmaf(-q, a, -1.0f));
+    return fmaf(-a, h, fmaxf(x, 0.f));
+}
+
 }  // namespace vp

@@ -57,20 +57,9 @@ template <int BK> __device__ __forceinline__ int swz(int row, int slot) {
     return BK == 64 ? (slot ^ ((row >> 1) & 7)) : (slot ^ (((row >> 3) & 1) * 3));
 }
 
-// nn.GELU(approximate='none') (vit.py:127) = x Phi(x).  With a = |x|: erfc(a / sqrt 2) = exp2(-a P(a)), P a degree-4
-// minimax fit on a <= 6.4 (|error of erfc| <= 6e-7, monotone beyond, so the tail underflows to 0), hence
-//   gelu(x) = max(x, 0) - (a / 2) exp2(-a P(a)):   8 VALU + one v_exp, |abs error| <= 1.2e-6 in fp32 arithmetic
-// -- far below the rounding of the 16-bit output.  (Abramowitz-Stegun 7.1.26 needs v_rcp + v_exp + 12 VALU and
-// was 48 us of the 318 us fc1 launch; ocml's erff ~3x more again.)
-__device__ __forceinline__ float gelu_erf(float x) {
-    const float a = fabsf(x);
-    float q = fmaf(a, 5.204574411e-04f, -7.397505390e-03f);
-    q = fmaf(q, a, 5.256122897e-02f);
-    q = fmaf(q, a, 4.592546873e-01f);
-    q = fmaf(q, a, 1.151091354e+00f);
-    const float e = __builtin_amdgcn_exp2f(-(q * a));
-    return fmaf(-0.5f * a, e, fmaxf(x, 0.f));
-}
+// nn.GELU(approximate='none') (vit.py:127): common.h::gelu_erf (degree-4 fit of erfc on a <= 6.4, |error of erfc| <= 6e-7, monotone
+// beyond, so the tail underflows to 0; Abramowitz-Stegun 7.1.26 needs v_rcp + v_exp + 12 VALU and was 48 us of the 318 us fc1 launch,
+// ocml's erff ~3x more again).
 
 // largest number of 16-row tiles per wave (dividing TJ) whose staged C rows fit in the tile ring's LDS
 template <class C, int ES> constexpr int epi_rows_per_pass() {

@@ -403,7 +403,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs g) {
                         }
                         if (EPI == EPI_BIAS_GELU) {
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) v[r] = gelu8(v[r]);
+                            for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
                         }
                         o[2 * f] = pack2<T>(v[0], v[1]);
                         o[2 * f + 1] = pack2<T>(v[2], v[3]);

@@ -31,15 +31,6 @@ __device__ __forceinline__ void bar() {
     __builtin_amdgcn_sched_barrier(0);
 }
 
-__device__ __forceinline__ float gelu8(float x) {   // identical to gemm.hip's gelu_erf
-    const float a = fabsf(x);
-    float q = fmaf(a, 5.204574411e-04f, -7.397505390e-03f);
-    q = fmaf(q, a, 5.256122897e-02f);
-    q = fmaf(q, a, 4.592546873e-01f);
-    q = fmaf(q, a, 1.151091354e+00f);
-    const float e = __builtin_amdgcn_exp2f(-(q * a));
-    return fmaf(-0.5f * a, e, fmaxf(x, 0.f));
-}
 
 __device__ __forceinline__ float row8_sum8(float x) {   // identical to gemm.hip's row8_sum
     x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xF, 0xF, true));

@@ -133,7 +133,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_wide_kernel(GemmArgs g) {
                 for (int r = 0; r < 4; ++r) v[r] = ln_fold(v[r], mu, sv[p][r], rs, b[p][r]);
                 if (EPI == EPI_BIAS_GELU) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = gelu8(v[r]);
+                    for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
                 }
                 o[2 * p] = pack2<T>(v[0], v[1]);
                 o[2 * p + 1] = pack2<T>(v[2], v[3]);
