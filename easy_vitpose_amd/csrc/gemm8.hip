@@ -511,8 +511,10 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs g) {
 #pragma unroll
                     for (int e = 0; e < 8; e += 2) { uint32_t h_, l_; split_planes2<T>(v[e], v[e + 1], h_, l_); oh[e >> 1] = h_; ol[e >> 1] = l_; }   // clamps v to the 16-bit range (statistics below see the stored value)
                     if (!(VP_ABLATE(g) & 8)) {
-                        *(u32x4*)(out_hi + orow_q[q] + n0 + ch * 8) = oh;
-                        *(u32x4*)(out_lo + orow_q[q] + n0 + ch * 8) = ol;
+                        size_t so = orow_q[q] + n0 + ch * 8;
+                        if (VP_ABLATE(g) & 128) so &= (size_t)0xFFFF8;   // tools/resid_store_probe.py: every store lands in the first 2 MB of the planes (stays in L2)
+                        *(u32x4*)(out_hi + so) = oh;
+                        *(u32x4*)(out_lo + so) = ol;
                     }
                     float s1s = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
                     s1s = row8_sum8(s1s);
