@@ -30,7 +30,9 @@
 //  * the LDS image of a slot is lane-linear (global_load_lds writes wave base + lane * 16): the XOR swizzle of the
 //    16-byte k-slots is applied to the per-lane SOURCE address and again on the ds_read_b128 fragment reads.
 //  * persistent workgroups: the ring runs on across tile boundaries (the next tile's first two K-tiles stream in during
-//    the last phases and the epilogue of the current one).
+//    the last phases and the epilogue of the current one).  At a tile's end the two wave groups re-align for the epilogue (group 0 waits
+//    one barrier) and fall one barrier apart again after it: run one after the other, each wave alone on its SIMD, the two groups'
+//    epilogues cost twice their store latency.
 //  * W rows are PERMUTED on their way into LDS (free: the source address of a DMA lane is arbitrary) so that the 4 * TI
 //    accumulator values a lane holds for one output row are CONSECUTIVE columns: the 16-bit epilogues (qkv, fc1) store
 //    straight from registers as 16-byte pieces that complete 128-byte lines -- no LDS round trip, no epilogue barrier.
@@ -47,6 +49,7 @@
 #ifndef VP_G8_RESD
 #define VP_G8_RESD 1
 #endif
+
 
 
 namespace vp {
@@ -282,6 +285,11 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs g) {
         // (the same for the epilogue's per-lane offsets: rebuilt per tile from opaque copies of the lane coordinates)
         int frow_e = frow, fg_e = fg;
         asm volatile("" : "+v"(frow_e), "+v"(fg_e));
+        // Both wave groups run their epilogues TOGETHER: group 0 waits one barrier for group 1 here, group 1 falls one barrier behind again
+        // at the end.  One barrier apart and with no barrier inside it, the epilogues of the two groups ran one AFTER the other -- each
+        // wave alone on its SIMD, held ~350 cycles by every 1 KiB store instruction (16 per wave) with nobody to issue beside it.
+        // (round 3: fc1 -4.6 %, qkv -2.5 %, bit-identical; profiles/gemm8_sched_r3.txt)
+        if constexpr (!RESID_LDS) { if (!wr) bar(); }
         if constexpr (RESID && !RESID_LDS) {
             // ---- residual epilogue straight from registers (EPI_BIAS_RESID_LN on 256 x 256 tiles) ----
             // lane (fg_e, frow_e): rows m0 + (J >> 2) 128 + wr 64 + (J & 3) 16 + frow_e, columns nb .. nb + 15 (W rows are permuted on their
@@ -549,6 +557,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs g) {
                 }
             }
         }
+        if constexpr (!RESID_LDS) { if (wr) bar(); }   // stagger again: waves 4-7 one barrier behind waves 0-3
         if (!has_next) break;
         t += tw.nloc;
         m0 = nm0;
