@@ -379,11 +379,62 @@ __global__ __launch_bounds__(NW * 64, 1) void issue_probe32_kernel(int iters, fl
 // 170 + (0 | 1 | 2: 8 / 4 / 2 independent accumulators) (+ 4: two waves per SIMD): the 32x32x16 probe, nanoseconds per round
 // 100 + mode (+ 32: two waves per SIMD; mode bit 4: 1 MiB = L2-resident buffers): issue probe, returns nanoseconds per round
 // 3 / 4 / 5 / 6: LDS-DMA stream from a 32 MiB / 1 GiB / 2 MiB / 256 KiB source, 2 blocks per CU (TB/s into LDS)
+// Store-path probe (tools/store_probe.py): every wave issues ROUNDS x 16 stores of 16 bytes per lane, the way a gemm8 epilogue does (one 128 x 64
+// block of 16-bit values per wave and "tile" = 16 KiB), into its own region of a buffer that is either small (stays in L2) or 1 GiB.
+// PAT 0: a store instruction = 1 KiB contiguous; 1: 16 rows x 64 contiguous bytes at a row stride (4 lanes of a row adjacent);
+// 2: 16 rows x four 16-byte pieces 32 bytes apart (the round-2/3 epilogue: a lane's 32 bytes of a row leave as two stores).
+template <int PAT>
+__global__ void store_probe_kernel(char* __restrict__ dst, size_t wave_bytes, size_t mask, int rounds, int row_stride) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nw = blockDim.x >> 6;
+    const size_t base = ((size_t)blockIdx.x * nw + wave) * wave_bytes;
+    const int frow = lane & 15, fg = lane >> 4;
+    u32x4 v = {(uint32_t)lane, 1u, 2u, 3u};
+    for (int r = 0; r < rounds; ++r) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {   // i = (row group J, half h)
+            const int J = i >> 1, h = i & 1;
+            size_t off;
+            if (PAT == 0) off = (size_t)i * 1024 + lane * 16;
+            else if (PAT == 1) off = (size_t)(J * 16 + frow) * row_stride + h * 64 + fg * 16;
+            else off = (size_t)(J * 16 + frow) * row_stride + fg * 32 + h * 16;
+            off = (base + (size_t)r * 16384 + off) & mask;
+            *(u32x4*)(dst + off) = v;
+            v[1] += 1;
+        }
+    }
+}
+
 hipError_t peak_bench(int kind, double* result) {
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
     float ms = 0.f;
-    if (kind == 0 || kind == 1) {
+    if (kind >= 200 && kind < 248) {
+        // 200 + 16 * waves code (0: 4, 1: 8, 2: 16 waves per CU) + 4 * pattern + 2 * (1 GiB instead of L2-resident) + (row stride 6144 instead of 128):
+        // returns shader-clock-independent NANOSECONDS per store instruction and CU
+        const int k = kind - 200, wc = k >> 4, pat = (k >> 2) & 3, big = (k >> 1) & 1, strided = k & 1;
+        const int nw = wc == 0 ? 4 : wc == 1 ? 8 : 16;
+        const size_t bytes = big ? ((size_t)1 << 30) : ((size_t)16 << 20);
+        char* dst;
+        hipMalloc((void**)&dst, bytes + (1 << 20));
+        const int rounds = 64;
+        const size_t wave_bytes = big ? bytes / (256 * nw) : (size_t)16384 * 4;   // small: every wave rewrites its own 64 KiB (chip total <= 16 MiB: L2 + MALL)
+        const int row_stride = strided ? 6144 : 128;
+        auto launch = [&]() {
+            if (pat == 0) hipLaunchKernelGGL(store_probe_kernel<0>, dim3(256), dim3(nw * 64), 0, nullptr, dst, wave_bytes, bytes - 1, rounds, row_stride);
+            else if (pat == 1) hipLaunchKernelGGL(store_probe_kernel<1>, dim3(256), dim3(nw * 64), 0, nullptr, dst, wave_bytes, bytes - 1, rounds, row_stride);
+            else hipLaunchKernelGGL(store_probe_kernel<2>, dim3(256), dim3(nw * 64), 0, nullptr, dst, wave_bytes, bytes - 1, rounds, row_stride);
+        };
+        for (int rep = 0; rep < 3; ++rep) {
+            hipEventRecord(e0, nullptr);
+            launch();
+            hipEventRecord(e1, nullptr);
+            hipDeviceSynchronize();
+        }
+        hipEventElapsedTime(&ms, e0, e1);
+        *result = (double)ms * 1e6 / ((double)rounds * 16 * nw);   // ns per store instruction and CU
+        hipFree(dst);
+    } else if (kind == 0 || kind == 1) {
         float* d;
         hipMalloc(&d, 4096);
         const int iters = 20000, blocks = 256 * 2;

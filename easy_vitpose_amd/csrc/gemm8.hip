@@ -77,11 +77,17 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs g) {
     const int slog = pslot ^ (((wave & 1) << 2) | (rip >> 1));   // logical k-slot this lane fetches (swizzled image)
     const uint32_t voff_x = g.a_blocked ? (uint32_t)(rip * 128 + slog * 16) : (uint32_t)(rip * K + slog * 8) * 2u;
     // W row permutation: LDS row r of half h holds tile column  wc(r) 16 TI + (rho >> 2) 4 TI + f 4 + (rho & 3),
-    // rho = r & 15, f = fragment index of the wave (half 0: (r >> 4) & 1, half 1: 2 + ...), wc(r) = owner wave column
+    // rho = r & 15, f = fragment index of the wave (half 0: (r >> 4) & 1, half 1: 2 + ...), wc(r) = owner wave column: a lane's 4 TI
+    // accumulator values of a row are 4 TI consecutive columns (residual epilogues).
+    // 16-bit epilogues (SPLIT): column  wc(r) 64 + (f >> 1) 32 + (rho >> 2) 8 + (f & 1) 4 + (rho & 3) -- a lane's 16 values are TWO runs of 8
+    // columns, 32 columns apart, so each of its two 16-byte stores of a row lands next to the other three lanes' pieces: a store
+    // instruction writes 16 rows x 64 CONTIGUOUS bytes instead of 16 rows x four 16-byte pieces 32 bytes apart (55-63 instead of 75
+    // cycles per instruction and CU: tools/store_probe.py, profiles/store_probe_r3.txt).
+    constexpr bool SPLIT = !RESID && C::TI == 4;
     const int rho = ((wave & 1) << 3) | rip;
-    const uint32_t voff_w = (uint32_t)(((rho >> 2) * 4 * C::TI + (rho & 3)) * K + slog * 8) * 2u;
+    const uint32_t voff_w = (uint32_t)(((rho >> 2) * (SPLIT ? 8 : 4 * C::TI) + (rho & 3)) * K + slog * 8) * 2u;
     const int wu0 = (wave >> 2) * 16 * C::TI + ((wave >> 1) & 1) * 4;                       // half 0, piece w   (piece w + 8: + 32 TI)
-    const int wu1 = (C::BN == 256) ? wu0 + 8 : (wave >> 1) * 16 * C::TI + 8;                // half 1, piece w   (BN = 256: piece w + 8: + 32 TI)
+    const int wu1 = SPLIT ? wu0 + 32 : (C::BN == 256) ? wu0 + 8 : (wave >> 1) * 16 * C::TI + 8;   // half 1, piece w   (BN = 256: piece w + 8: + 32 TI)
     const size_t xrow_bytes = g.a_blocked ? 128 : (size_t)K * 2;                            // bytes between consecutive rows of a piece
     const size_t x64 = g.a_blocked ? (size_t)(K >> 6) * 8192 : (size_t)64 * K * 2;          // + 64 rows
     const size_t xkt = g.a_blocked ? 8192 : 128;                                            // + one K-tile
@@ -372,20 +378,22 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs g) {
                 if (fg_e == 0 && store) *(float2*)(g.stats_out + ((size_t)m * gran + (nb >> 6)) * 2) = float2{s1, s2};
             }
         } else if constexpr (!RESID) {
-            // lane (fg_e, frow_e): rows m0 + (J >> 2) 128 + wr 64 + (J & 3) 16 + frow_e, columns n0 + wc 16 TI + fg_e 4 TI + [0, 4 TI).
+            // lane (fg_e, frow_e): rows m0 + (J >> 2) 128 + wr 64 + (J & 3) 16 + frow_e; columns (SPLIT, TI = 4) n0 + wc 64 + fg_e 8 + [0, 8) from
+            // fragments 0, 1 and + 32 + [0, 8) from fragments 2, 3; otherwise n0 + wc 16 TI + fg_e 4 TI + [0, 4 TI).
             // Every operand of the epilogue is loaded up front (one latency, not one per row group); the LayerNorm-consumer
             // variant is chosen by ONE wave-uniform branch around the whole block.
-            const int nb = n0 + wc * 16 * C::TI + fg_e * 4 * C::TI;
+            const int nb = SPLIT ? n0 + wc * 64 + fg_e * 8 : n0 + wc * 16 * C::TI + fg_e * 4 * C::TI;
+            auto fcol = [&](int f) { return SPLIT ? (f >> 1) * 32 + (f & 1) * 4 : f * 4; };   // first column of fragment f relative to nb
             const int mrow = m0 + wr * 64 + frow_e;
             auto epilogue = [&](auto LNc) {
                 constexpr bool LN = decltype(LNc)::value;
                 f32x4 bias4[C::TI], s4[LN ? C::TI : 1];
                 float2 st[LN ? 8 : 1];
 #pragma unroll
-                for (int f = 0; f < C::TI; ++f) bias4[f] = *(const f32x4*)(g.bias + nb + f * 4);
+                for (int f = 0; f < C::TI; ++f) bias4[f] = *(const f32x4*)(g.bias + nb + fcol(f));
                 if constexpr (LN) {
 #pragma unroll
-                    for (int f = 0; f < C::TI; ++f) s4[f] = *(const f32x4*)(g.ln_s + nb + f * 4);
+                    for (int f = 0; f < C::TI; ++f) s4[f] = *(const f32x4*)(g.ln_s + nb + fcol(f));
 #pragma unroll
                     for (int J = 0; J < 8; ++J) st[J] = *(const float2*)(g.rowstat + 2 * (size_t)(mrow + (J >> 2) * 128 + (J & 3) * 16));
                 }
@@ -421,10 +429,10 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs g) {
                         if constexpr (C::TI == 4) {
                             if (VP_ABLATE(g) & 64) {   // experiment: streaming (non-temporal) stores
                                 __builtin_nontemporal_store(u32x4{o[0], o[1], o[2], o[3]}, (u32x4*)dst);
-                                __builtin_nontemporal_store(u32x4{o[4], o[5], o[6], o[7]}, (u32x4*)(dst + 8));
+                                __builtin_nontemporal_store(u32x4{o[4], o[5], o[6], o[7]}, (u32x4*)(dst + 32));
                             } else {
                                 *(u32x4*)dst = u32x4{o[0], o[1], o[2], o[3]};
-                                *(u32x4*)(dst + 8) = u32x4{o[4], o[5], o[6], o[7]};
+                                *(u32x4*)(dst + 32) = u32x4{o[4], o[5], o[6], o[7]};   // SPLIT: the second run of 8 columns
                             }
                         } else {   // 12 columns = 24 bytes, 8-byte aligned
                             *(u32x2*)dst = u32x2{o[0], o[1]};
