@@ -32,6 +32,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+NOMINAL_SCLK_MHZ = 2400.0
 PEAK_MFMA_16BIT = 2.5e15   # dense bf16/fp16 MFMA peak, MI355X_MICROARCH.md (256 CU x 4096 FLOP/clk x 2.4 GHz)
 PEAK_HBM = 8.0e12
 
@@ -251,6 +252,54 @@ def pmc_traffic(args, kernel_name):
     return None, f'not measured: kernel not found in {PMC_FILE}'
 
 
+def clock_power_under_load(step, fence, seconds=3.0):
+    """Shader clock and board power WHILE the step runs (untimed pass after the measurement): `rocm-smi --showclocks --showpower --json`
+    polled back to back from a thread while the main thread replays the step.  The MI355X hits its board power limit under the encoder
+    GEMMs and drops the shader clock well below the 2.4 GHz that the 2.5 PFLOP/s peak assumes (profiles/clock_power_r3.txt); the
+    bench line carries the measured clock so that `roofline.frac` (against the nominal peak) can be read beside the peak the chip can
+    sustain at that clock.  Returns None when rocm-smi is missing or prints something unexpected."""
+    import shutil
+    import subprocess
+    import threading
+    smi = shutil.which('rocm-smi') or '/opt/rocm/bin/rocm-smi'
+    if not os.path.exists(smi):
+        return None
+    samples, stop = [], [False]
+
+    def num(txt):
+        t = ''.join(ch for ch in str(txt) if ch.isdigit() or ch == '.')
+        return float(t) if t else None
+
+    def poll():
+        while not stop[0]:
+            t0 = time.time()
+            try:
+                o = subprocess.run([smi, '--showclocks', '--showpower', '--json'], capture_output=True, text=True, timeout=20).stdout
+                card = next(iter(json.loads(o).values()))
+                samples.append((t0, time.time(), num(card.get('sclk clock speed:')), num(card.get('Current Socket Graphics Package Power (W)'))))
+            except Exception:
+                return
+    th = threading.Thread(target=poll, daemon=True)
+    fence()
+    t_begin = time.time()
+    th.start()
+    while time.time() - t_begin < seconds:
+        for _ in range(8):
+            step()
+        fence()
+    t_end = time.time()
+    stop[0] = True
+    th.join(timeout=30)
+    ok = [(c, p) for a, b, c, p in samples if a >= t_begin + 0.5 and b <= t_end and c and p]
+    if not ok:
+        return None
+    sclk = sum(c for c, _ in ok) / len(ok)
+    return {'sclk_mhz': round(sclk, 0), 'board_power_w': round(sum(p for _, p in ok) / len(ok), 0), 'samples': len(ok),
+            'nominal_sclk_mhz': NOMINAL_SCLK_MHZ,
+            'mfma_peak_at_sclk_tflops': round(PEAK_MFMA_16BIT / 1e12 * sclk / NOMINAL_SCLK_MHZ, 1),
+            'source': f'rocm-smi polled during an untimed {seconds:.0f} s replay of the step (whole step, not one kernel)'}
+
+
 def host_path_rate(eng, crops_u8, K, seconds=1.5):
     """persons/s of the host-visible path: uint8 crops in pinned host memory -> keypoints in pinned host memory, through
     vp_infer_submit / vp_infer_wait (H2D of batch i+1 and D2H of batch i-1 under the compute of batch i)."""
@@ -304,6 +353,7 @@ def main():
     ap.add_argument('--input', default='f32', choices=['f32', 'u8'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-host-path', action='store_true')
+    ap.add_argument('--no-clock', action='store_true', help='skip the untimed 3 s pass that samples shader clock / board power with rocm-smi')
     ap.add_argument('--breakdown', action='store_true', help='extra untimed pass with every kernel family timed (stderr)')
     ap.add_argument('--strong', action='store_true', help='also measure the strong-scaled frame of BASELINE configs[3] (default when WORLD_SIZE > 1)')
     ap.add_argument('--force-dist', action='store_true', help='run the RCCL code path (process group, all-gather, barrier) even with one rank')
@@ -382,6 +432,10 @@ def main():
     if rank == 0 and world == 1 and not args.no_host_path:
         host_rate = host_path_rate(eng, crops_u8, K)
 
+    clock = None
+    if rank == 0 and world == 1 and not args.no_clock:
+        clock = clock_power_under_load(step, fence)
+
     strong = None
     if use_dist and (world > 1 or args.strong):
         strong = strong_scaling_config4(world, rank, dev, args.dtype)
@@ -426,6 +480,7 @@ def main():
                          'launches': d['launches'], 'avg_launch_ms': round(d['ms'] / max(d['launches'], 1), 5),
                          'flops_per_launch': d['flops'] / max(d['launches'], 1),
                          'algorithmic_bytes_per_launch': d['bytes'] / max(d['launches'], 1)},
+            'clock_under_load': clock,
             'encoder_gemms': per_family,
             'step_ms': {'p10': round(float(np.percentile(step_ms, 10)), 4), 'p50': round(float(np.percentile(step_ms, 50)), 4),
                         'p90': round(float(np.percentile(step_ms, 90)), 4), 'n': len(step_ms), 'note': 'one host synchronisation per step'},

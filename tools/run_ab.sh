@@ -5,7 +5,7 @@ A=$1; B=$2; R=${3:-3}
 rm -f gpurun_out/ab_${A}_${B}.txt
 for r in $(seq $R); do for L in $A $B; do
   echo -n "$L: " >> gpurun_out/ab_${A}_${B}.txt
-  VP_HIP_LIB=$PWD/easy_vitpose_amd/_lib/ab/$L.so timeout 300 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-host-path --breakdown 2>&1 | python -c "
+  VP_HIP_LIB=$PWD/easy_vitpose_amd/_lib/ab/$L.so timeout 300 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-host-path --no-clock --breakdown 2>&1 | python -c "
 import sys,json
 o=''
 for l in sys.stdin:

@@ -12,7 +12,7 @@ timeout 200 python tools/gemm8_timeline.py >> $O 2>&1
 A=bnd0; B=bnd1; Cc=bnd2
 for r in 1 2 3; do for L in bnd0 bnd1 bnd2; do
   echo -n "$L: " >> $O
-  VP_HIP_LIB=$PWD/easy_vitpose_amd/_lib/ab/$L.so timeout 300 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-host-path --breakdown 2>&1 | python -c "
+  VP_HIP_LIB=$PWD/easy_vitpose_amd/_lib/ab/$L.so timeout 300 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-host-path --no-clock --breakdown 2>&1 | python -c "
 import sys,json
 o=''
 for l in sys.stdin:

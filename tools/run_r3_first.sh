@@ -11,7 +11,7 @@ for r in 1 2; do
   for L in product tools; do
     if [ $L = tools ]; then export VP_HIP_LIB=$T; else unset VP_HIP_LIB; fi
     echo -n "$L: " >> gpurun_out/r3_ab_product_tools.txt
-    timeout 300 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-host-path --breakdown 2>&1 | python -c "
+    timeout 300 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-host-path --no-clock --breakdown 2>&1 | python -c "
 import sys,json
 o=''
 for l in sys.stdin:

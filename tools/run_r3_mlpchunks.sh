@@ -19,7 +19,7 @@ PY
 done
 for r in 1 2 3; do for n in 1 3 2 4; do
   echo -n "chunks $n: " >> $O
-  VP_MLP_CHUNKS=$n timeout 300 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-host-path --breakdown 2>&1 | python -c "
+  VP_MLP_CHUNKS=$n timeout 300 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-host-path --no-clock --breakdown 2>&1 | python -c "
 import sys,json
 o=''
 for l in sys.stdin:

@@ -4,7 +4,7 @@ T=$PWD/easy_vitpose_amd/_lib/libvitpose_hip_tools.so
 for r in 1 2; do
   for cfg in "none" "2:64" "1:64" "2:64,1:64"; do
     echo -n "nt stores [$cfg]: " >> gpurun_out/r3_nt.txt
-    VP_HIP_LIB=$T VP_ABLATE_FAM=$cfg timeout 300 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-host-path --breakdown 2>&1 | python -c "
+    VP_HIP_LIB=$T VP_ABLATE_FAM=$cfg timeout 300 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-host-path --no-clock --breakdown 2>&1 | python -c "
 import sys,json
 o=''
 for l in sys.stdin:

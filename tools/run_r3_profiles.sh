@@ -13,7 +13,7 @@ for cfg in "--variant s --dataset coco --batch 256" "--variant h --dataset whole
            "--variant l --dataset coco_25 --batch 8 --input u8" "--variant b --dataset ap10k --batch 512" "--variant b --dataset coco --batch 256 --dtype bf16" \
            "--variant b --dataset coco --batch 256 --input u8"; do
   echo "== $cfg"
-  timeout 300 python bench.py $cfg --steps 30 --warmup 5 --no-cpu-baseline --no-host-path 2>/dev/null | python -c "
+  timeout 300 python bench.py $cfg --steps 30 --warmup 5 --no-cpu-baseline --no-host-path --no-clock 2>/dev/null | python -c "
 import sys,json
 for l in sys.stdin:
     if l.startswith('{'):
@@ -24,4 +24,4 @@ done
 } > gpurun_out/r3_other_configs.txt 2>&1
 cat gpurun_out/r3_other_configs.txt
 timeout 300 python tools/stream_bench.py --frames 100 > gpurun_out/r3_stream.txt 2>&1; tail -3 gpurun_out/r3_stream.txt
-timeout 300 python bench.py --force-dist --strong --steps 20 --warmup 5 --no-cpu-baseline --no-host-path > gpurun_out/r3_force_dist.json 2> gpurun_out/r3_force_dist.err; echo "force-dist rc=$?"; head -c 600 gpurun_out/r3_force_dist.json; tail -3 gpurun_out/r3_force_dist.err
+timeout 300 python bench.py --force-dist --strong --steps 20 --warmup 5 --no-cpu-baseline --no-host-path --no-clock > gpurun_out/r3_force_dist.json 2> gpurun_out/r3_force_dist.err; echo "force-dist rc=$?"; head -c 600 gpurun_out/r3_force_dist.json; tail -3 gpurun_out/r3_force_dist.err

@@ -9,7 +9,7 @@ for v in l h; do
 done
 for r in 1 2 3; do for L in old new; do for v in l h; do
   echo -n "$L $v: " >> $O
-  VP_HIP_LIB=$PWD/easy_vitpose_amd/_lib/ab/$L.so timeout 300 python bench.py --variant $v --batch 128 --steps 15 --warmup 3 --no-cpu-baseline --no-host-path --breakdown 2>&1 | python -c "
+  VP_HIP_LIB=$PWD/easy_vitpose_amd/_lib/ab/$L.so timeout 300 python bench.py --variant $v --batch 128 --steps 15 --warmup 3 --no-cpu-baseline --no-host-path --no-clock --breakdown 2>&1 | python -c "
 import sys,json
 o=''
 for l in sys.stdin:

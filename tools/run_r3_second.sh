@@ -8,7 +8,7 @@ for r in 1 2; do
   for cfg in "7 0" "7 1" "15 0" "15 1"; do
     set -- $cfg
     echo -n "GEMM8=$1 TOUCH=$2: " >> gpurun_out/r3_touch_bench.txt
-    VP_HIP_LIB=$T VP_GEMM8=$1 VP_TOUCH=$2 timeout 300 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-host-path --breakdown 2>&1 | python -c "
+    VP_HIP_LIB=$T VP_GEMM8=$1 VP_TOUCH=$2 timeout 300 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-host-path --no-clock --breakdown 2>&1 | python -c "
 import sys,json
 o=''
 for l in sys.stdin:

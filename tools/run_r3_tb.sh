@@ -11,7 +11,7 @@ done
 grep -v amdgpu.ids gpurun_out/r3_tb_check.txt
 for r in 1 2 3; do for L in tb1 tb2; do
   echo -n "$L: " >> gpurun_out/r3_tb_bench.txt
-  VP_HIP_LIB=$AB/$L.so timeout 300 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-host-path --breakdown 2>&1 | python -c "
+  VP_HIP_LIB=$AB/$L.so timeout 300 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-host-path --no-clock --breakdown 2>&1 | python -c "
 import sys,json
 o=''
 for l in sys.stdin:
