@@ -404,3 +404,22 @@ def test_host_resize_matches_independent_c_oracle():
     img = rng.integers(0, 256, (90, 70, 3), dtype=np.uint8)
     for dw, dh in [(35, 45), (140, 180), (71, 89), (1, 1)]:
         assert np.array_equal(resize_linear_u8(img, (dw, dh)), ref(img, (dw, dh))), (dw, dh)
+
+
+def test_bench_clock_probe_degrades_to_none_without_a_gpu(monkeypatch, tmp_path):
+    """bench.py's clock / power pass (rocm-smi polled while the step replays) must never break the bench line: without a GPU (this
+    container) or without rocm-smi it returns None; with a well-formed rocm-smi answer it reports the mean clock and the MFMA peak
+    the chip can sustain at that clock."""
+    import sys
+    import time
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    r0 = bench.clock_power_under_load(lambda: time.sleep(0.005), lambda: None, seconds=0.8)
+    assert r0 is None or isinstance(r0, dict)
+    fake = tmp_path / 'rocm-smi'
+    fake.write_text('#!/bin/sh\necho \'{"card0": {"sclk clock speed:": "(1800Mhz)", "Current Socket Graphics Package Power (W)": "1300.0"}}\'\n')
+    fake.chmod(0o755)
+    monkeypatch.setenv('PATH', f'{tmp_path}:{os.environ["PATH"]}')
+    r = bench.clock_power_under_load(lambda: time.sleep(0.005), lambda: None, seconds=1.5)
+    assert r is not None and r['sclk_mhz'] == 1800 and r['board_power_w'] == 1300
+    assert abs(r['mfma_peak_at_sclk_tflops'] - 2500.0 * 1800 / 2400) < 0.1
