@@ -253,7 +253,10 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs g) {
     if (VP_STAGGER(g) > 0) {   // experiment (VP_G8_STAGGER): XCD x -- or, from 100 on, workgroup j of every XCD -- starts n * 1024 cycles late so
                            // that the epilogues no longer coincide.  Measured at every step: the launch gets slower by exactly the delay
                            // (the epilogue's cost is per CU, not a shared-bandwidth burst: profiles/gemm8_sections_r2.txt)
-        const int n = (VP_STAGGER(g) >= 100) ? (blockIdx.x >> 3) * (VP_STAGGER(g) - 100) : (blockIdx.x & 7) * VP_STAGGER(g);   // >= 100: per workgroup inside its XCD
+        const bool short_list = (tw.cnt - tw.j0 + tw.nloc - 1) / tw.nloc < (tw.cnt + tw.nloc - 1) / tw.nloc;   // one tile less than the longest list
+        const int n = (VP_STAGGER(g) >= 300) ? (short_list ? VP_STAGGER(g) - 300 : 0)   // >= 300: only the workgroups with a tile of slack
+                    : (VP_STAGGER(g) >= 200) ? ((blockIdx.x >> 3) & 1) * (VP_STAGGER(g) - 200)   // >= 200: every second workgroup of an XCD, all by the same delay (two phases)
+                    : (VP_STAGGER(g) >= 100) ? (blockIdx.x >> 3) * (VP_STAGGER(g) - 100) : (blockIdx.x & 7) * VP_STAGGER(g);   // >= 100: per workgroup inside its XCD
         for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(16);
     }
     // ---- prologue of the first tile: K-tile 0 complete, K-tile 1 in flight ----
