@@ -358,6 +358,21 @@ __global__ __launch_bounds__(C::NT, 2) void gemm_kernel(GemmArgs g) {
 #pragma unroll
     for (int s = 0; s < C::STAGES - 1; ++s)
         if (s < nk) stage(s, s);
+    if constexpr (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) {
+        // Fused LayerNorm at small batch (GemmArgs::ln_part): the tile's BM rows are merged ONCE, one row per thread, while the first
+        // k-blocks stream in, and shared through LDS behind the operand ring -- not once per lane and fragment row in the epilogue
+        // (16 x redundant, round 2: slower than the separate ln_finalize launch it replaced).  Same ln_merge, same bits.
+        if (g.ln_part) {
+            float2* st = (float2*)(smem + C::LDS);
+            for (int r = tid; r < C::BM; r += C::NT) {
+                int m = m0 + r;
+                if (m > g.M - 1) m = g.M - 1;
+                float mean, rstd;
+                ln_merge(g.ln_part + (size_t)m * g.ln_tiles * 2, g.ln_tiles, g.ln_inv_d, mean, rstd);
+                st[r] = float2{mean, rstd};
+            }
+        }
+    }
     int buf = 0, pbuf = C::STAGES - 1;
     for (int kt = 0; kt < nk; ++kt) {
         // tile kt has landed once at most STAGES-2 younger tiles are still in flight
@@ -680,8 +695,10 @@ __global__ __launch_bounds__(C::NT, 2) void gemm_kernel(GemmArgs g) {
             for (int j = 0; j < C::TJ; ++j) {
                 int m = m0 + wm * C::WM + j * 16 + frow;
                 if (m > g.M - 1) m = g.M - 1;
-                if (g.ln_part) {
-                    ln_merge(g.ln_part + (size_t)m * g.ln_tiles * 2, g.ln_tiles, g.ln_inv_d, ln_mean[j], ln_rstd[j]);
+                if (g.ln_part) {   // merged once per tile row in the prologue (see there)
+                    const float2 s2 = ((const float2*)(smem + C::LDS))[wm * C::WM + j * 16 + frow];
+                    ln_mean[j] = s2.x;
+                    ln_rstd[j] = s2.y;
                 } else {
                     ln_mean[j] = g.rowstat[2 * (size_t)m];
                     ln_rstd[j] = g.rowstat[2 * (size_t)m + 1];
@@ -1131,12 +1148,14 @@ static hipError_t launch(const GemmArgs& a, hipStream_t s) {
     auto kern = gemm_kernel<T, EPI, AMODE, C>;
     // fused head: the staged 16-bit tile [BM][BN + 8] may be larger than the operand ring
     constexpr int LDS_BYTES = (EPI == EPI_DECONV_FINAL && C::BM * (C::BN * 2 + 16) > C::LDS) ? C::BM * (C::BN * 2 + 16) : C::LDS;
-    static_assert(LDS_BYTES <= 160 * 1024, "LDS");
+    constexpr int LN_STAT_BYTES = C::BM * 8;   // (mean, rstd) per tile row behind the ring: used when GemmArgs::ln_part is set
+    static_assert(LDS_BYTES + LN_STAT_BYTES <= 160 * 1024, "LDS");
+    if (a.ln_part && (C::PIPE == 2 || C::PIPE == 3 || C::DIRECT)) return hipErrorInvalidValue;   // the prologue merge lives in the generic loop
     static bool attr_done[64] = {};   // the > 64 KiB LDS opt-in is a per-device function attribute
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (dev < 0 || dev >= 64 || !attr_done[dev]) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES + LN_STAT_BYTES);
         if (e != hipSuccess) return e;
         if (dev >= 0 && dev < 64) attr_done[dev] = true;
     }
@@ -1149,7 +1168,7 @@ static hipError_t launch(const GemmArgs& a, hipStream_t s) {
     if (a.desc)
         snprintf(a.desc, a.desc_cap, "gemm_kernel<%s, %d, %d, TileCfg<%d, %d, %d, %d, %d, %d, %d, %d>>", std::is_same<T, F16>::value ? "F16" : "BF16", EPI,
                  AMODE, C::BM, C::BN, C::BK, C::WM, C::WN, C::STAGES, C::PIPE, C::DIRECT);
-    hipLaunchKernelGGL(kern, grid, dim3(C::NT), LDS_BYTES, s, g);
+    hipLaunchKernelGGL(kern, grid, dim3(C::NT), LDS_BYTES + (a.ln_part ? LN_STAT_BYTES : 0), s, g);
     return hipGetLastError();
 }
 

@@ -89,6 +89,35 @@ def test_small_batch_graph_replay_is_bit_identical(monkeypatch):
     assert not np.array_equal(o2, ref)
 
 
+@pytest.mark.parametrize('variant,dataset,dtype,n', [('s', 'coco', 'fp16', 8), ('b', 'coco', 'fp16', 16), ('l', 'coco_25', 'fp16', 3), ('b', 'coco', 'bf16', 1)])
+def test_small_batch_statistics_fold_is_bit_identical(monkeypatch, variant, dataset, dtype, n):
+    """Batches of <= 8 crops (default threshold; VP_FOLD_STATS=n moves it): qkv / fc1 merge the LayerNorm partial statistics of their
+    tile rows themselves (gemm.hip prologue, GemmArgs::ln_part) instead of 2 x depth ln_finalize launches.  Same ln_merge, so heatmaps
+    and keypoints agree bit for bit with the ln_finalize path (VP_FOLD_STATS=0), and the launches really disappear."""
+    shp, sd, _ = weights(variant, dataset)
+    crops = synthetic_crops(n, 33, 'blobs')
+    monkeypatch.setenv('VP_GRAPH', '0')
+    monkeypatch.setenv('VP_FOLD_STATS', '0')
+    eng = VitPoseHip(shp, sd, dtype=dtype, max_batch=n)
+    eng.set_profiling(True)
+    ref_kp, ref_hm = eng.infer(crops), eng.heatmaps(crops)
+    ref_launches = eng.profile()['layernorm']['launches']
+    eng.close()
+    if n <= 8:
+        monkeypatch.delenv('VP_FOLD_STATS')          # the default threshold covers it
+    else:
+        monkeypatch.setenv('VP_FOLD_STATS', '64')    # measured slower than ln_finalize from 16 crops on: off by default, same bits
+    eng = VitPoseHip(shp, sd, dtype=dtype, max_batch=n)
+    eng.set_profiling(True)
+    kp, hm = eng.infer(crops), eng.heatmaps(crops)
+    launches = eng.profile()['layernorm']['launches']
+    eng.close()
+    assert np.array_equal(hm, ref_hm)
+    assert np.array_equal(kp, ref_kp)
+    assert np.isfinite(hm).all() and float(np.abs(hm).max()) > 0
+    assert ref_launches == 2 * (2 * shp.depth + 1) and launches == 2, (ref_launches, launches)   # only last_norm is left (two forward passes)
+
+
 @pytest.mark.parametrize('variant,dataset,dtype,n', [('s', 'coco', 'fp16', 64), ('s', 'wholebody', 'fp16', 48), ('b', 'coco_25', 'bf16', 44)])
 def test_fused_head_is_bit_identical(monkeypatch, variant, dataset, dtype, n):
     """Batches of >= 43 crops run deconv2 + final 1x1 conv as ONE kernel (gemm.hip EPI_DECONV_FINAL: the 256-channel activations
