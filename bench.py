@@ -14,7 +14,8 @@ weights of that architecture, synthetic uniform-noise crops.
 
 Prints ONE JSON line on rank 0 with `roofline` (the GEMM family with the largest share of the step, timed live
 with HIP events on the library's stream inside the timed region; `kernel` = what the library says it launched, `traffic` read
-from the committed PMC passes as `traffic_source` states), `step_ms` percentiles, `host_persons_per_sec` (N=1: pinned host
+from the committed PMC passes as `traffic_source` states), `clock_under_load` (N=1: shader clock and board power sampled with rocm-smi during an
+untimed replay of the step -- the chip runs these GEMMs at its power limit, well below the 2.4 GHz behind `roofline.peak`), `step_ms` percentiles, `host_persons_per_sec` (N=1: pinned host
 buffers -> keypoints on the host through the asynchronous double-buffered entry, PCIe included), `cpu_baseline` +
 `cpu_baseline_batched` (the oracle's torch-CPU path per crop / in batches of 16 on this box's host cores, rank 0, N=1 only,
 bounded samples), and for N > 1 `per_rank_ms_per_step` / `allgather_ms` / `strong_scaling_config4`.
