@@ -13,6 +13,12 @@ import sys
 import threading
 import time
 
+try:
+    import torch   # first: torch initialises HIP itself (importing it after the library's first HIP calls found no device)
+    torch.cuda.init()
+except Exception:   # noqa: BLE001
+    torch = None
+
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 if 'VP_HIP_LIB' not in os.environ:
@@ -142,5 +148,29 @@ if os.environ.get('VP_PROBE_SET', 'main') == 'main':
     loop('MFMA-only 32x32x16 (TF)', peak(1))
     loop('float4 copy 1 GiB (TB/s)', peak(4))
     loop('float4 copy 32 MiB (TB/s)', peak(3))
-for ab in (0, 1, 8, 9):   # plain-epilogue fc1 shape with pieces removed (timing AND power)
+for ab in ((0, 1, 8, 9) if os.environ.get('VP_PROBE_SET', 'main') != 'torch' else ()):   # plain-epilogue fc1 shape with pieces removed (timing AND power)
     loop(f'fc1 shape, bias epilogue, ablate {ab}', gemm1(0, 16 | (ab << 8), 8, M, 3072, 768))
+
+if os.environ.get('VP_PROBE_SET', 'main') in ('main', 'torch'):   # the vendor library's plain GEMM (torch.mm -> hipBLASLt / rocBLAS) on the same shapes: is IT power-capped too?
+    try:
+        dev = torch.device('cuda:0')
+
+        def mm(M_, N_, K_):
+            a = (torch.rand((M_, K_), device=dev, dtype=torch.float32) * 2 - 1).half()
+            b = (torch.rand((K_, N_), device=dev, dtype=torch.float32) * 2 - 1).half()
+            c = torch.empty((M_, N_), device=dev, dtype=torch.float16)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
+            def f():
+                e0.record()
+                for _ in range(50):
+                    torch.mm(a, b, out=c)
+                e1.record()
+                torch.cuda.synchronize()
+                return e0.elapsed_time(e1) / 50 * 1e3
+            return f
+        loop('torch.mm fp16 49152 x 3072 x 768 (plain)', mm(M, 3072, 768))
+        loop('torch.mm fp16 49152 x 3072 x 4096 (plain)', mm(M, 3072, 4096))
+        loop('torch.mm fp16 8192^3 (plain)', mm(8192, 8192, 8192))
+    except Exception as e:   # noqa: BLE001
+        print('torch.mm probe skipped:', e)
