@@ -359,16 +359,24 @@ __global__ __launch_bounds__(C::NT, 2) void gemm_kernel(GemmArgs g) {
     for (int s = 0; s < C::STAGES - 1; ++s)
         if (s < nk) stage(s, s);
     if constexpr (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) {
-        // Fused LayerNorm at small batch (GemmArgs::ln_part): the tile's BM rows are merged ONCE, one row per thread, while the first
-        // k-blocks stream in, and shared through LDS behind the operand ring -- not once per lane and fragment row in the epilogue
-        // (16 x redundant, round 2: slower than the separate ln_finalize launch it replaced).  Same ln_merge, same bits.
+        // Fused LayerNorm at small batch (GemmArgs::ln_part): the tile's BM rows are merged ONCE, one row per thread, and shared through LDS
+        // behind the operand ring -- not once per lane and fragment row in the epilogue (16 x redundant, round 2: slower than the separate
+        // ln_finalize launch it replaced).  The tile's block of partial statistics ([BM][ln_tiles][2] floats, contiguous) comes in by
+        // LDS-DMA into the ring slot the prologue leaves free (slot STAGES-1 is first written after the K-loop's first barrier), next to the
+        // first k-blocks; one thread per row then runs ln_merge on it -- the same code ln_finalize_kernel runs: same bits.
         if (g.ln_part) {
+            char* pb = smem + (C::STAGES - 1) * C::STAGE_BYTES;
+            const int row_bytes = g.ln_tiles * 8;
+            const int valid = min(C::BM, g.M - m0) * row_bytes;            // rows past M are never stored: left as they are
+            const char* src = (const char*)(g.ln_part + (size_t)m0 * g.ln_tiles * 2);
+            for (int i = wave * 1024; i < C::BM * row_bytes; i += C::NWAVES * 1024)
+                if (i + lane * 16 < valid) glds16(src + i + lane * 16, pb + i);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
             float2* st = (float2*)(smem + C::LDS);
             for (int r = tid; r < C::BM; r += C::NT) {
-                int m = m0 + r;
-                if (m > g.M - 1) m = g.M - 1;
                 float mean, rstd;
-                ln_merge(g.ln_part + (size_t)m * g.ln_tiles * 2, g.ln_tiles, g.ln_inv_d, mean, rstd);
+                ln_merge((const float*)(pb + r * row_bytes), g.ln_tiles, g.ln_inv_d, mean, rstd);
                 st[r] = float2{mean, rstd};
             }
         }
@@ -1151,6 +1159,7 @@ static hipError_t launch(const GemmArgs& a, hipStream_t s) {
     constexpr int LN_STAT_BYTES = C::BM * 8;   // (mean, rstd) per tile row behind the ring: used when GemmArgs::ln_part is set
     static_assert(LDS_BYTES + LN_STAT_BYTES <= 160 * 1024, "LDS");
     if (a.ln_part && (C::PIPE == 2 || C::PIPE == 3 || C::DIRECT)) return hipErrorInvalidValue;   // the prologue merge lives in the generic loop
+    if (a.ln_part && C::BM * a.ln_tiles * 8 > C::STAGE_BYTES) return hipErrorInvalidValue;                  // ... and borrows one ring slot
     static bool attr_done[64] = {};   // the > 64 KiB LDS opt-in is a per-device function attribute
     int dev = 0;
     (void)hipGetDevice(&dev);

@@ -113,7 +113,7 @@ struct vp_ctx {
     int graph_max_n = 16;
     int graph_max_n_stats = 8;        // batches of <= this many crops: the consumer GEMMs (qkv, fc1) merge the LayerNorm partial statistics of their tile rows
                                       // themselves (once per row and tile, in the prologue: gemm.hip) and the 2 x depth ln_finalize launches disappear -- same
-                                      // ln_merge, bit-identical.  Measured (profiles/fold_stats_r3.txt): -5...-10 % per step at 1-8 crops, +10...+20 % at
+                                      // ln_merge, bit-identical.  Measured (profiles/fold_stats_r3.txt): -7...-12 % per step at 1-8 crops, +0...+20 % at
                                       // 16-48 (every column tile merges its rows again): threshold 8.  VP_FOLD_STATS=n moves it (0 = always ln_finalize).
                                       // Round 2 merged per LANE in the epilogue (16 x redundant): slower than ln_finalize even at 8 crops (3.89 vs 2.97 ms).
     hipEvent_t ev_in = nullptr, ev_out = nullptr;   // vp_infer_device_stream: ordering against the caller's stream
