@@ -45,6 +45,7 @@
 // bit-identical to the 2-phase kernels: that identity is the race screen (tools/gemm8_check.py, tests).
 #include <cstdio>
 
+#include <cstdlib>
 #include "gemm8_common.h"
 #ifndef VP_G8_RESD
 #define VP_G8_RESD 1
@@ -594,6 +595,10 @@ static hipError_t launch8(const GemmArgs& a, hipStream_t s) {
     }
     const int tiles = (a.M / C::BM) * (a.N / C::BN);
     int grid = tiles < 256 ? tiles : 256;
+#ifdef VP_TOOLS   // experiment (tools/two_lane_probe.py): persistent grids of fewer workgroups, so that two handles' launches can share the chip
+    static const int max_wgs = [] { const char* e = getenv("VP_G8_WGS"); return e ? atoi(e) : 256; }();
+    if (grid > max_wgs) grid = max_wgs;
+#endif
     grid &= ~7;
     if (grid < 8) return hipErrorInvalidValue;
     if (a.desc) snprintf(a.desc, a.desc_cap, "gemm8_kernel<%s, %d, G8<%d>>", std::is_same<T, F16>::value ? "F16" : "BF16", EPI, C::BN);
