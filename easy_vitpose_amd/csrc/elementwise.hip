@@ -495,8 +495,9 @@ hipError_t peak_bench(int kind, double* result) {
         hipEventElapsedTime(&ms, e0, e1);
         *result = (double)ms * 1e6 / iters;
         hipFree(dst); hipFree(src); hipFree(d);
-    } else if (kind >= 3 && kind <= 6) {
-        const size_t bytes = kind == 3 ? ((size_t)32 << 20) : kind == 4 ? ((size_t)1 << 30) : kind == 5 ? ((size_t)2 << 20) : ((size_t)256 << 10);
+    } else if (kind >= 3 && kind <= 12) {   // 7 .. 12: 64 / 96 / 128 / 192 / 256 / 384 MiB sources: is the 256 MB memory-side cache faster than HBM?
+        static const size_t mib[] = {32, 1024, 2, 0, 64, 96, 128, 192, 256, 384};
+        const size_t bytes = kind == 6 ? ((size_t)256 << 10) : (mib[kind - 3] << 20);
         char* a; float* d;
         hipMalloc(&a, bytes); hipMalloc(&d, 4096);
         hipMemset(a, 1, bytes);

@@ -1772,7 +1772,7 @@ VP_API int vp_dbg_fp8_gemm(int32_t device, int32_t M, int32_t N, int32_t K, cons
 
 // Calibration: kind 0/1 = MFMA-only loop (16x16x32 / 32x32x16 f16) in TFLOP/s, 2 = float4 copy in TB/s (read+write).
 VP_API int vp_dbg_peak(int32_t device, int32_t kind, double* result) {
-    if (!result || kind < 0 || (kind > 6 && (kind < 100 || kind >= 248 || (kind >= 164 && kind < 170) || (kind >= 178 && kind < 200)))) return fail(nullptr, VP_ERR_INVALID, "bad argument");
+    if (!result || kind < 0 || (kind > 12 && (kind < 100 || kind >= 248 || (kind >= 164 && kind < 170) || (kind >= 178 && kind < 200)))) return fail(nullptr, VP_ERR_INVALID, "bad argument");
     if (hipSetDevice(device) != hipSuccess) return fail(nullptr, VP_ERR_HIP, "no HIP device");
     hipError_t e = vp::peak_bench(kind, result);
     return e == hipSuccess ? VP_OK : fail(nullptr, VP_ERR_HIP, hipGetErrorString(e));
