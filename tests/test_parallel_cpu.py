@@ -45,9 +45,8 @@ def _worker(rank, world, port, n, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('n', [0, 1, 2, 7, 64])
-def test_sharded_equals_single_process(n):
-    world = 2
+@pytest.mark.parametrize('n,world', [(0, 2), (1, 2), (2, 2), (7, 2), (64, 2), (7, 3), (2, 3), (64, 3)])
+def test_sharded_equals_single_process(n, world):
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = _free_port()
