@@ -223,8 +223,12 @@ __global__ __launch_bounds__(256, QT == 3 ? 2 : 3) void attention_kernel(const u
 
 template <class Ty, int HD>
 static hipError_t launch(const uint16_t* qkv, uint16_t* out, int B, int D, int heads, hipStream_t s) {
+#ifdef VP_TOOLS   // measurement build: VP_ATTN_QT=3 runs the three-query-tiles-at-a-time variant (fewest LDS reads, 2 blocks per CU: measured slower)
     static const int qt = [] { const char* e = getenv("VP_ATTN_QT"); return e ? atoi(e) : 1; }();
     auto kern = qt == 1 ? attention_kernel<Ty, HD, 1> : attention_kernel<Ty, HD, 3>;
+#else
+    auto kern = attention_kernel<Ty, HD, 1>;
+#endif
     const float scale = 1.0f / sqrtf((float)HD);   // head_dim ** -0.5, vit.py:156
     hipLaunchKernelGGL(kern, dim3(B * heads), dim3(256), AttnCfg<HD>::LDS, s, qkv, out, D, heads,
                        scale * 1.4426950408889634f);
