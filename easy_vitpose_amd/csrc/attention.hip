@@ -56,11 +56,17 @@ __global__ __launch_bounds__(256, QT == 3 ? 2 : 3) void attention_kernel(const u
     char* Vs = smem + C::K_BYTES;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // Block order.  The dispatcher puts block i on XCD i % 8, so the heads of one crop land on eight different L2s.  When a head slice is not a whole
-    // number of 128-byte lines (HD = 32: 64 bytes, HD = 80: 160 bytes) neighbouring heads share lines: an XCD-contiguous order lets one L2 fetch them
-    // once (measured, profiles/attention_order_r3.txt: ViTPose-S attention -11.5 %, ViTPose-H -4 %).  With whole-line slices (HD = 64) the plain
-    // order is faster (B +11 %, L +4 % with the remap) and stays.
+    // number of 128-byte lines (HD = 32: 64 bytes, HD = 80: 160 bytes) neighbouring heads share lines.  Inside super-groups of 32 block ids every XCD
+    // therefore takes FOUR consecutive (crop, head) ids: neighbours meet in one L2 and the eight XCDs still walk the same crops together
+    // (profiles/attention_order_r3.txt: attention of ViTPose-S -15 %, of ViTPose-H -6 %; an XCD-contiguous order over the whole launch gains less,
+    // and with whole-line slices -- HD = 64 -- it is 4-11 % SLOWER than the plain order, which stays there).
     constexpr bool REMAP = (HD * 2) % 128 != 0;
-    const int bid = REMAP ? xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+    int bid = blockIdx.x;
+    if constexpr (REMAP) {
+        constexpr int P = 4, G = 8 * P;
+        const int i = blockIdx.x;
+        if (i < (int)(gridDim.x / G) * G) bid = (i & ~(G - 1)) | ((i & 7) * P) | ((i >> 3) & (P - 1));
+    }
     const int b = bid / heads, h = bid % heads;
     const size_t ld = (size_t)3 * D;
     const uint16_t* qbase = qkv + (size_t)b * T * ld + (size_t)h * HD;
