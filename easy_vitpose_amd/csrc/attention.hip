@@ -49,7 +49,7 @@ __device__ __forceinline__ u32x2 lds_read_tr16(const char* p) {
 
 template <class Ty, int HD, int QT>
 __global__ __launch_bounds__(256, QT == 3 ? 2 : 3) void attention_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out,
-                                                            int D, int heads, float scale_log2e) {
+                                                            int D, int heads, float scale_log2e, int blocked) {
     using C = AttnCfg<HD>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* Ks = smem;
@@ -69,9 +69,14 @@ __global__ __launch_bounds__(256, QT == 3 ? 2 : 3) void attention_kernel(const u
     }
     const int b = bid / heads, h = bid % heads;
     const size_t ld = (size_t)3 * D;
-    const uint16_t* qbase = qkv + (size_t)b * T * ld + (size_t)h * HD;
-    const uint16_t* kbase = qbase + D;
-    const uint16_t* vbase = qbase + 2 * D;
+    // row `key` of this (crop, head)'s q / k / v slab (sel = 0 / 1 / 2).  Row-major qkv [M][3 D]: 2 HD bytes of a 6 D-byte row.  `blocked` (HD = 64 only):
+    // qkv as the GEMM's 64 x 64-blocked output [M / 64][3 D / 64][64][64] -- a slab is then three CONTIGUOUS 8 KiB blocks instead of 192 pieces of 128 bytes
+    // 6 D bytes apart, for the qkv epilogue's stores as for the loads here
+    auto rowp = [&](int sel, int key) -> const uint16_t* {
+        if (HD == 64 && blocked)
+            return qkv + ((((size_t)(b * 3 + (key >> 6)) * (ld >> 6)) + (size_t)sel * (D >> 6) + h) << 12) + ((key & 63) << 6);
+        return qkv + ((size_t)b * T + key) * ld + (size_t)sel * D + (size_t)h * HD;
+    };
 
     // ---- global loads first (K, Q, then V), LDS writes as the data arrives: K is written and made visible before
     //      V has to be there, so the first QK^T + softmax run in the shadow of the V loads ----
@@ -86,7 +91,7 @@ __global__ __launch_bounds__(256, QT == 3 ? 2 : 3) void attention_kernel(const u
     for (int i = 0; i < NKL; ++i) {
         const int c = tid + i * 256, key = c / CHP, ch = c % CHP;
         kreg[i] = u32x4{0, 0, 0, 0};
-        if (c < T * CHP && ch < CH) kreg[i] = *(const u32x4*)(kbase + (size_t)key * ld + ch * 8);
+        if (c < T * CHP && ch < CH) kreg[i] = *(const u32x4*)(rowp(1, key) + ch * 8);
     }
     // Q fragments (B operand: lane holds Q[q = lane&15][d = kk*32 + (lane>>4)*8 .. +7]).  A wave owns 3 query
     // tiles, processed QT at a time: QT = 3 shares every K / V^T fragment read between the tiles (fewest LDS reads,
@@ -98,13 +103,13 @@ __global__ __launch_bounds__(256, QT == 3 ? 2 : 3) void attention_kernel(const u
 #pragma unroll
         for (int kk = 0; kk < KS; ++kk) {
             const int d = kk * 32 + fg * 8;
-            qf_all[t][kk] = (d < HD) ? *(const u32x4*)(qbase + (size_t)q * ld + d) : u32x4{0, 0, 0, 0};
+            qf_all[t][kk] = (d < HD) ? *(const u32x4*)(rowp(0, q) + d) : u32x4{0, 0, 0, 0};
         }
     }
 #pragma unroll
     for (int i = 0; i < NVL; ++i) {
         const int c = tid + i * 256, key = c / CH, ch = c % CH;
-        if (c < T * CH) vreg[i] = *(const u32x4*)(vbase + (size_t)key * ld + ch * 8);
+        if (c < T * CH) vreg[i] = *(const u32x4*)(rowp(2, key) + ch * 8);
     }
 #pragma unroll
     for (int i = 0; i < NKL; ++i) {
@@ -234,7 +239,7 @@ __global__ __launch_bounds__(256, QT == 3 ? 2 : 3) void attention_kernel(const u
 }
 
 template <class Ty, int HD>
-static hipError_t launch(const uint16_t* qkv, uint16_t* out, int B, int D, int heads, hipStream_t s) {
+static hipError_t launch(const uint16_t* qkv, uint16_t* out, int B, int D, int heads, hipStream_t s, int blocked) {
 #ifdef VP_TOOLS   // measurement build: VP_ATTN_QT=3 runs the three-query-tiles-at-a-time variant (fewest LDS reads, 2 blocks per CU: measured slower)
     static const int qt = [] { const char* e = getenv("VP_ATTN_QT"); return e ? atoi(e) : 1; }();
     auto kern = qt == 1 ? attention_kernel<Ty, HD, 1> : attention_kernel<Ty, HD, 3>;
@@ -242,17 +247,18 @@ static hipError_t launch(const uint16_t* qkv, uint16_t* out, int B, int D, int h
     auto kern = attention_kernel<Ty, HD, 1>;
 #endif
     const float scale = 1.0f / sqrtf((float)HD);   // head_dim ** -0.5, vit.py:156
+    if (blocked && HD != 64) return hipErrorInvalidValue;
     hipLaunchKernelGGL(kern, dim3(B * heads), dim3(256), AttnCfg<HD>::LDS, s, qkv, out, D, heads,
-                       scale * 1.4426950408889634f);
+                       scale * 1.4426950408889634f, blocked);
     return hipGetLastError();
 }
 
-hipError_t attention_launch(int dtype, const uint16_t* qkv, uint16_t* out, int B, int D, int heads, hipStream_t s) {
+hipError_t attention_launch(int dtype, const uint16_t* qkv, uint16_t* out, int B, int D, int heads, hipStream_t s, int qkv_blocked) {
     const int hd = D / heads;
     if (hd * heads != D) return hipErrorInvalidValue;
 #define VP_ATT(HD)                                                                           \
     if (hd == HD)                                                                            \
-        return dtype == DT_F16 ? launch<F16, HD>(qkv, out, B, D, heads, s) : launch<BF16, HD>(qkv, out, B, D, heads, s);
+        return dtype == DT_F16 ? launch<F16, HD>(qkv, out, B, D, heads, s, qkv_blocked) : launch<BF16, HD>(qkv, out, B, D, heads, s, qkv_blocked);
     VP_ATT(32) VP_ATT(64) VP_ATT(80)
 #undef VP_ATT
     return hipErrorInvalidValue;

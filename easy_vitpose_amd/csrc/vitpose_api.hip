@@ -90,6 +90,7 @@ struct vp_ctx {
     bool persist_gemm = true;         // qkv / fc1 as persistent workgroups at large batch (VP_PERSIST=0: one tile per workgroup)
     int order_mask = 8;               // tile walk last-to-first per GEMM: bit0 qkv, bit1 proj, bit2 fc1, bit3 fc2 (VP_ORDER)
     bool blocked_hid = true;          // mlp hidden activations in the 64x64-blocked layout (VP_BLOCKED_HID=0: row-major)
+    bool blocked_qkv = true;          // qkv in the same blocked layout when the head dim is 64 (a (crop, head) slab = three contiguous 8 KiB blocks; VP_BLOCKED_QKV=0: row-major)
     bool fuse_ln = true;              // LayerNorm folded into the GEMMs on both sides of it (VP_FUSE_LN=0: standalone passes)
     float *ln_part = nullptr, *rowstat = nullptr;   // partial row statistics [M][D/64][2], (mean, rstd) [M][2]
     // asynchronous host path (vp_infer_submit / vp_infer_wait): two slots, each with its own device staging, so that the
@@ -475,6 +476,7 @@ int forward_chunk(vp_ctx* c, const void* d_crops, int fmt, int n, bool want_toke
     LAUNCH(c, VP_PROF_IM2COL, 0.0, in_b + 2.0 * M * 768, vp::im2col_launch(c->dtype, d_crops, fmt, c->hid, n, c->stream, flip));
     int rc;
     size_t plane = 0;   // != 0: the residual stream c->x is held as two 16-bit planes (fused-LayerNorm path)
+    const bool qkv_blocked = c->blocked_qkv && D / c->heads == 64;
     if (c->fuse_ln) {
         // LayerNorm folded into the GEMMs on both sides of it.  The residual stream is kept as two 16-bit planes
         // (x = hi + lo, same bytes as fp32, >= 22 significant bits): every producer (patch embed, attn.proj,
@@ -496,11 +498,11 @@ int forward_chunk(vp_ctx* c, const void* d_crops, int fmt, int n, bool want_toke
         if ((rc = finalize())) return rc;
         for (int l = 0; l < c->L; ++l) {
             const Block& b = c->blocks[l];
-            LnFuse cq; cq.rowstat = c->rowstat; cq.ln_s = b.s_qkv; cq.reverse = (c->order_mask & 1) != 0;
+            LnFuse cq; cq.rowstat = c->rowstat; cq.ln_s = b.s_qkv; cq.reverse = (c->order_mask & 1) != 0; cq.out_blocked = qkv_blocked;
             if (fold_stats) { cq.rowstat = nullptr; cq.ln_part = c->ln_part; cq.ln_tiles = D / 64; }
             if ((rc = gemm(c, VP_PROF_GEMM_QKV, vp::EPI_BIAS, xh, b.w_qkv, b.b_qkv, c->qkv, nullptr, M, 3 * D, D, 3 * D, 0, 0, 0, &cq))) return rc;
             LAUNCH(c, VP_PROF_ATTN, 4.0 * 192 * 192 * (double)D * n, 8.0 * M * D,
-                   vp::attention_launch(c->dtype, c->qkv, c->y, n, D, c->heads, c->stream));
+                   vp::attention_launch(c->dtype, c->qkv, c->y, n, D, c->heads, c->stream, qkv_blocked ? 1 : 0));
             LnFuse pp = prod; pp.reverse = (c->order_mask & 2) != 0;
             if ((rc = gemm(c, VP_PROF_GEMM_PROJ, vp::EPI_BIAS_RESID_LN, c->y, b.w_proj, b.b_proj, c->x, c->x, M, D, D, D, 0, 0, 0, &pp))) return rc;
             if ((rc = finalize())) return rc;
@@ -517,9 +519,10 @@ int forward_chunk(vp_ctx* c, const void* d_crops, int fmt, int n, bool want_toke
         const Block& b = c->blocks[l];
         LAUNCH(c, VP_PROF_LAYERNORM, 0.0, 6.0 * M * D,
                vp::layernorm_launch(c->dtype, c->x, b.ln1_g, b.ln1_b, c->y, nullptr, M, D, c->stream));
-        if ((rc = gemm(c, VP_PROF_GEMM_QKV, vp::EPI_BIAS, c->y, b.w_qkv, b.b_qkv, c->qkv, nullptr, M, 3 * D, D, 3 * D))) return rc;
+        LnFuse q0; q0.out_blocked = qkv_blocked;
+        if ((rc = gemm(c, VP_PROF_GEMM_QKV, vp::EPI_BIAS, c->y, b.w_qkv, b.b_qkv, c->qkv, nullptr, M, 3 * D, D, 3 * D, 0, 0, 0, &q0))) return rc;
         LAUNCH(c, VP_PROF_ATTN, 4.0 * 192 * 192 * (double)D * n, 8.0 * M * D,
-               vp::attention_launch(c->dtype, c->qkv, c->y, n, D, c->heads, c->stream));
+               vp::attention_launch(c->dtype, c->qkv, c->y, n, D, c->heads, c->stream, qkv_blocked ? 1 : 0));
         if ((rc = gemm(c, VP_PROF_GEMM_PROJ, vp::EPI_BIAS_RESID, c->y, b.w_proj, b.b_proj, c->x, c->x, M, D, D, D))) return rc;
         LAUNCH(c, VP_PROF_LAYERNORM, 0.0, 6.0 * M * D,
                vp::layernorm_launch(c->dtype, c->x, b.ln2_g, b.ln2_b, c->y, nullptr, M, D, c->stream));
@@ -659,6 +662,7 @@ int vp_create(vp_handle* out, const vp_config* cfg) {
     if (const char* f = getenv("VP_GRAPH")) c->graph_max_n = atoi(f) == 1 ? 16 : atoi(f);   // 0 = off, 1 = default, n > 1: capture chunks of up to n crops
     if (const char* f = getenv("VP_FUSE_HEAD")) c->fuse_head = atoi(f) != 0;
     if (const char* f = getenv("VP_FOLD_STATS")) c->graph_max_n_stats = atoi(f);
+    if (const char* f = getenv("VP_BLOCKED_QKV")) c->blocked_qkv = atoi(f) != 0;
 #ifdef VP_TOOLS   // development switches of the measurement build (tools/)
     if (const char* f = getenv("VP_BLOCKED_HID")) c->blocked_hid = atoi(f) != 0;
     if (const char* f = getenv("VP_ORDER")) c->order_mask = atoi(f);
