@@ -89,6 +89,25 @@ def test_small_batch_graph_replay_is_bit_identical(monkeypatch):
     assert not np.array_equal(o2, ref)
 
 
+@pytest.mark.parametrize('variant,dataset,dtype,n', [('b', 'coco', 'fp16', 44), ('l', 'coco_25', 'fp16', 5), ('b', 'coco', 'bf16', 9)])
+def test_blocked_qkv_layout_is_bit_identical(monkeypatch, variant, dataset, dtype, n):
+    """Head dim 64: the qkv GEMM writes its output in the 64 x 64-blocked layout and the attention kernel reads a (crop, head)'s q / k / v as three
+    contiguous 8 KiB blocks (VP_BLOCKED_QKV, default on).  Only addresses change: heatmaps and keypoints agree bit for bit with the row-major layout."""
+    shp, sd, _ = weights(variant, dataset)
+    crops = synthetic_crops(n, 17, 'blobs')
+    monkeypatch.setenv('VP_BLOCKED_QKV', '0')
+    eng = VitPoseHip(shp, sd, dtype=dtype, max_batch=n)
+    ref_kp, ref_hm = eng.infer(crops), eng.heatmaps(crops)
+    eng.close()
+    monkeypatch.delenv('VP_BLOCKED_QKV')
+    eng = VitPoseHip(shp, sd, dtype=dtype, max_batch=n)
+    kp, hm = eng.infer(crops), eng.heatmaps(crops)
+    eng.close()
+    assert np.array_equal(hm, ref_hm)
+    assert np.array_equal(kp, ref_kp)
+    assert np.isfinite(hm).all() and float(np.abs(hm).max()) > 0
+
+
 @pytest.mark.parametrize('variant,dataset,dtype,n', [('s', 'coco', 'fp16', 8), ('b', 'coco', 'fp16', 16), ('l', 'coco_25', 'fp16', 3), ('b', 'coco', 'bf16', 1)])
 def test_small_batch_statistics_fold_is_bit_identical(monkeypatch, variant, dataset, dtype, n):
     """Batches of <= 8 crops (default threshold; VP_FOLD_STATS=n moves it): qkv / fc1 merge the LayerNorm partial statistics of their
