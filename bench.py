@@ -354,6 +354,7 @@ def main():
     ap.add_argument('--input', default='f32', choices=['f32', 'u8'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-host-path', action='store_true')
+    ap.add_argument('--no-live-events', action='store_true', help='no HIP-event records in the timed region (roofline timing from the warm-up pass): lets VP_GRAPH=n replay a hipGraph at large batches')
     ap.add_argument('--no-clock', action='store_true', help='skip the untimed 3 s pass that samples shader clock / board power with rocm-smi')
     ap.add_argument('--breakdown', action='store_true', help='extra untimed pass with every kernel family timed (stderr)')
     ap.add_argument('--strong', action='store_true', help='also measure the strong-scaled frame of BASELINE configs[3] (default when WORLD_SIZE > 1)')
@@ -408,7 +409,7 @@ def main():
     # the largest share of the step is reported as the dominant kernel (rocprofv3 --stats of the same command: profiles/)
     # batches of <= 16 crops replay a captured hipGraph, which event records inside the chunk would switch off: there the timed
     # region runs unprofiled and the dominant kernel's launch time is the warm-up pass's (roofline.timed = 'warm-up pass')
-    live = B > 16
+    live = B > 16 and not args.no_live_events
     eng.set_profiling([dom] if live else False)     # timed region: only the dominant family carries event records (2 per launch)
     eng.reset_profile()
     if not live:
@@ -477,7 +478,7 @@ def main():
                          'what': FAMILIES[dom],
                          'achieved': round(ach / 1e12, 2), 'peak': PEAK_MFMA_16BIT / 1e12, 'unit': 'TFLOP/s',
                          'frac': round(ach / PEAK_MFMA_16BIT, 4), 'traffic': traffic, 'traffic_source': traffic_source,
-                         'timed': 'live, HIP events around every launch of the timed region' if B > 16 else 'warm-up pass (the timed region replays a hipGraph)',
+                         'timed': 'live, HIP events around every launch of the timed region' if live else 'warm-up pass (no event records in the timed region)',
                          'launches': d['launches'], 'avg_launch_ms': round(d['ms'] / max(d['launches'], 1), 5),
                          'flops_per_launch': d['flops'] / max(d['launches'], 1),
                          'algorithmic_bytes_per_launch': d['bytes'] / max(d['launches'], 1)},
