@@ -423,3 +423,14 @@ def test_bench_clock_probe_degrades_to_none_without_a_gpu(monkeypatch, tmp_path)
     r = bench.clock_power_under_load(lambda: time.sleep(0.005), lambda: None, seconds=1.5)
     assert r is not None and r['sclk_mhz'] == 1800 and r['board_power_w'] == 1300
     assert abs(r['mfma_peak_at_sclk_tflops'] - 2500.0 * 1800 / 2400) < 0.1
+
+
+def test_tools_and_bench_scripts_compile():
+    """tools/*.py, bench.py and __graft_entry__.py are the recipes behind profiles/: they must at least parse (they only run on a GPU box)."""
+    import glob
+    import py_compile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    files = sorted(glob.glob(os.path.join(root, 'tools', '*.py'))) + [os.path.join(root, 'bench.py'), os.path.join(root, '__graft_entry__.py')]
+    assert len(files) > 20
+    for f in files:
+        py_compile.compile(f, doraise=True, cfile=os.devnull)
