@@ -427,10 +427,10 @@ def test_bench_clock_probe_degrades_to_none_without_a_gpu(monkeypatch, tmp_path)
 
 def test_tools_and_bench_scripts_compile():
     """tools/*.py, bench.py and __graft_entry__.py are the recipes behind profiles/: they must at least parse (they only run on a GPU box)."""
+    import ast
     import glob
-    import py_compile
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     files = sorted(glob.glob(os.path.join(root, 'tools', '*.py'))) + [os.path.join(root, 'bench.py'), os.path.join(root, '__graft_entry__.py')]
     assert len(files) > 20
     for f in files:
-        py_compile.compile(f, doraise=True, cfile=os.devnull)
+        ast.parse(open(f).read(), filename=f)
