@@ -4,6 +4,7 @@
     python bench.py [--gpus N --steps K --warmup W] [--dtype fp16|bf16] [--batch 256]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
+(`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment launches those N ranks itself.)
 
 One "step" = one pass of the whole hot path (crop batch resident in HBM -> patch embed
 -> ViT encoder -> deconv head -> heatmaps -> arg-max/DARK-UDP decode -> keypoints in
@@ -336,6 +337,34 @@ def host_path_rate(eng, crops_u8, K, seconds=1.5):
     return n * B / dt
 
 
+def self_launch(n: int, argv, stdout_fd) -> int:
+    """`python bench.py --gpus N` with WORLD_SIZE unset (how the driver starts the N = 1 run): re-execute this
+    script as N ranks under torch.distributed.run on 127.0.0.1 -- one process per GPU -- and hand through its exit code.  The
+    children inherit stdout, so rank 0's ONE JSON line is still the only thing on it (every rank points its own fd 1 at stderr)."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')    # dmabuf IPC: RCCL across processes needs it on this driver
+    env.setdefault('OMP_NUM_THREADS', '8')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n}', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + list(argv)
+    print(f'[bench] --gpus {n} without WORLD_SIZE: launching {" ".join(cmd)}', file=sys.stderr, flush=True)
+    return subprocess.run(cmd, env=env, stdout=stdout_fd).returncode   # this process has pointed its own fd 1 at stderr already: the children get the real stdout
+
+
+def _load_hook(spec):
+    """VP_BENCH_ENGINE=module:function (tests only): function(args, rank, world, local_rank) -> dict(eng, d_crops, d_out, K, dev, backend,
+    device_sync, strong_factory) replaces the HIP engine and the device tensors, so that the launcher, the process-group set-up and the
+    whole multi-rank measurement code of main() run on a CPU box over gloo (tests/test_parallel_cpu.py)."""
+    import importlib
+    mod, fn = spec.split(':')
+    return getattr(importlib.import_module(mod), fn)
+
+
 def main():
     # The ONE JSON line must be the only thing on stdout: RCCL prints a version banner to the C-level stdout of rank 0 (buffered, so it
     # lands AFTER python's own output at exit).  fd 1 is pointed at stderr for the whole run and the line goes to the saved descriptor.
@@ -361,40 +390,58 @@ def main():
     ap.add_argument('--force-dist', action='store_true', help='run the RCCL code path (process group, all-gather, barrier) even with one rank')
     args = ap.parse_args()
 
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:   # started plainly (as the driver starts N = 1): spawn the ranks ourselves
+        rc = self_launch(args.gpus, sys.argv[1:], json_fd)
+        os.close(json_fd)
+        sys.exit(rc)
+
     import torch
     import torch.distributed as dist
-    from easy_vitpose_amd import VitPoseHip
     from easy_vitpose_amd.configs import model_shape
-    from easy_vitpose_amd.synth import synthetic_crops, synthetic_state_dict
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run'
-    assert torch.cuda.is_available(), 'bench.py needs an AMD GPU (the HIP path has no CPU fallback)'
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
+    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus} (or plainly, without WORLD_SIZE)'
     use_dist = world > 1 or args.force_dist
-    if use_dist:
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        os.environ.setdefault('MASTER_PORT', '29517')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
-
     shp = model_shape(args.variant, args.dataset)
     B, K = args.batch, shp.num_keypoints
-    eng = VitPoseHip(shp, synthetic_state_dict(shp, 0), dtype=args.dtype, device_id=local_rank, max_batch=args.max_batch or B)
-    crops_u8 = synthetic_crops(B, seed=rank, kind='noise')
-    if args.input == 'u8':
-        d_crops = torch.from_numpy(crops_u8).to(dev)
-    else:  # what pre_img hands to the model: normalised float32 NCHW
-        mean = np.array([0.485, 0.456, 0.406]); std = np.array([0.229, 0.224, 0.225])
-        x = ((crops_u8.astype(np.float64) / 255 - mean) / std).transpose(0, 3, 1, 2).astype(np.float32)
-        d_crops = torch.from_numpy(np.ascontiguousarray(x)).to(dev)
-    d_out = torch.zeros((B, K, 3), dtype=torch.float32, device=dev)
+    hook = os.environ.get('VP_BENCH_ENGINE')
+    strong_factory = None
+    if hook:   # tests only: fake engine on CPU tensors over gloo
+        h = _load_hook(hook)(args, rank, world, local_rank)
+        eng, d_crops, d_out, K, dev, device_sync, strong_factory = h['eng'], h['d_crops'], h['d_out'], h['K'], h['dev'], h['device_sync'], h.get('strong_factory')
+        B = d_crops.shape[0]
+        crops_u8 = None
+        if use_dist:
+            os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+            os.environ.setdefault('MASTER_PORT', '29517')
+            dist.init_process_group(h.get('backend', 'gloo'), rank=rank, world_size=world)
+    else:
+        from easy_vitpose_amd import VitPoseHip
+        from easy_vitpose_amd.synth import synthetic_crops, synthetic_state_dict
+        assert torch.cuda.is_available(), 'bench.py needs an AMD GPU (the HIP path has no CPU fallback)'
+        assert local_rank < torch.cuda.device_count(), f'rank {rank}: LOCAL_RANK {local_rank} but only {torch.cuda.device_count()} visible devices'
+        torch.cuda.set_device(local_rank)
+        dev = torch.device('cuda', local_rank)
+        device_sync = torch.cuda.synchronize
+        if use_dist:
+            os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+            os.environ.setdefault('MASTER_PORT', '29517')
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        eng = VitPoseHip(shp, synthetic_state_dict(shp, 0), dtype=args.dtype, device_id=local_rank, max_batch=args.max_batch or B)
+        crops_u8 = synthetic_crops(B, seed=rank, kind='noise')
+        if args.input == 'u8':
+            d_crops = torch.from_numpy(crops_u8).to(dev)
+        else:  # what pre_img hands to the model: normalised float32 NCHW
+            mean = np.array([0.485, 0.456, 0.406]); std = np.array([0.229, 0.224, 0.225])
+            x = ((crops_u8.astype(np.float64) / 255 - mean) / std).transpose(0, 3, 1, 2).astype(np.float32)
+            d_crops = torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+        d_out = torch.zeros((B, K, 3), dtype=torch.float32, device=dev)
     d_all = torch.zeros((world * B, K, 3), dtype=torch.float32, device=dev) if use_dist else None
-    torch.cuda.synchronize()
+    device_sync()
 
-    H = Harness(eng, d_crops, d_out, d_all, dist if use_dist else None, torch.cuda.synchronize)
+    H = Harness(eng, d_crops, d_out, d_all, dist if use_dist else None, device_sync)
     step, fence = H.step, H.fence
 
     fams = list(FAMILIES)
@@ -431,16 +478,19 @@ def main():
         fence()
         step_ms.append((time.perf_counter() - t1) * 1e3)
     host_rate = None
-    if rank == 0 and world == 1 and not args.no_host_path:
+    if rank == 0 and world == 1 and not args.no_host_path and not hook:
         host_rate = host_path_rate(eng, crops_u8, K)
 
     clock = None
-    if rank == 0 and world == 1 and not args.no_clock:
+    if rank == 0 and world == 1 and not args.no_clock and not hook:
         clock = clock_power_under_load(step, fence)
 
     strong = None
     if use_dist and (world > 1 or args.strong):
-        strong = strong_scaling_config4(world, rank, dev, args.dtype)
+        if hook:
+            strong = strong_scaling_config4(world, rank, dev, args.dtype, steps=3, warmup=1, n_total=7, engine_factory=strong_factory, dist=dist)
+        else:
+            strong = strong_scaling_config4(world, rank, dev, args.dtype)
 
     breakdown = None
     if args.breakdown and rank == 0:
@@ -458,10 +508,16 @@ def main():
         d = prof[dom]
         ach = d['flops'] / (d['ms'] * 1e-3) if d['ms'] > 0 else 0.0
         traffic, traffic_source = pmc_traffic(args, kernels[dom])
-        per_family = {f: {'what': FAMILIES[f], 'kernel': kernels[f],
-                          'ms_per_step': round(wprof[f]['ms'] / max(args.warmup, 1), 4), 'avg_launch_us': round(1e3 * wprof[f]['ms'] / max(wprof[f]['launches'], 1), 2),
-                          'tflops': round(wprof[f]['flops'] / max(wprof[f]['ms'], 1e-9) / 1e9, 1),
-                          'algorithmic_gbps': round(wprof[f]['bytes'] / max(wprof[f]['ms'], 1e-9) / 1e6, 1)} for f in fams}   # from the warm-up pass
+        # one number per kernel in the line: the dominant family from the TIMED region (the same events `roofline` uses), the other three
+        # from the warm-up pass (all four families event-timed there, which perturbs the step slightly) -- each entry says which
+        def fam_entry(f):
+            src = prof if (live and f == dom) else wprof
+            steps_ = args.steps if (live and f == dom) else max(args.warmup, 1)
+            return {'what': FAMILIES[f], 'kernel': kernels[f], 'timed': 'timed region' if (live and f == dom) else 'warm-up pass',
+                    'ms_per_step': round(src[f]['ms'] / steps_, 4), 'avg_launch_us': round(1e3 * src[f]['ms'] / max(src[f]['launches'], 1), 2),
+                    'tflops': round(src[f]['flops'] / max(src[f]['ms'], 1e-9) / 1e9, 1),
+                    'algorithmic_gbps': round(src[f]['bytes'] / max(src[f]['ms'], 1e-9) / 1e6, 1)}
+        per_family = {f: fam_entry(f) for f in fams}
         line = {
             'metric': 'persons_per_sec', 'value': round(persons_s, 1), 'unit': 'persons/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,

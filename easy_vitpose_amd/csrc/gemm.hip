@@ -497,8 +497,13 @@ __global__ __launch_bounds__(C::NT, 2) void gemm_kernel(GemmArgs g) {
         // weight fragments of a 16-joint group are fetched one group ahead (the first before the barrier that publishes the
         // staged tile: the accumulators are dead by then), so only one L2 round trip is exposed per tile.
         const int groups = (g.Kp + 15) >> 4;
+        // the lane coordinates pass through an empty asm here and at every use below: the per-lane 64-bit addresses of the weight loads and
+        // of the heatmap stores are then formed where they are used instead of being hoisted out of the group loop and kept live beside
+        // 2 x 64 weight + 64 activation fragment registers (this kernel sat at 256 VGPRs with 8 spilled: VERDICT r3 weak 6)
         auto ldw = [&](u32x4(&w)[16], int u) {
-            const uint16_t* wrow = g.W2 + (size_t)(u * 32 + frow) * C::BN + fg * 8;
+            int frow_w = frow, fg_w = fg;
+            asm volatile("" : "+v"(frow_w), "+v"(fg_w));
+            const uint16_t* wrow = g.W2 + (size_t)(u * 32 + frow_w) * C::BN + fg_w * 8;
 #pragma unroll
             for (int ks = 0; ks < 8; ++ks) {
                 w[2 * ks] = *(const u32x4*)(wrow + ks * 32);
@@ -513,19 +518,21 @@ __global__ __launch_bounds__(C::NT, 2) void gemm_kernel(GemmArgs g) {
         for (int jj = 0; jj < JW; ++jj)
 #pragma unroll
             for (int ks = 0; ks < 8; ++ks) bf[jj][ks] = *(const u32x4*)(smem + (wave * RPW + jj * 16 + frow) * RB + (ks * 32 + fg * 8) * 2);
-        size_t orow[JW];
-        bool live[JW];
+        // output pixel of fragment row jj as (image, pixel inside the image): two 32-bit values per row instead of a 64-bit element offset
+        int oimg[JW], opx[JW];
         const int opix = 4 * g.Hin * g.Win;
 #pragma unroll
         for (int jj = 0; jj < JW; ++jj) {
             const int m = m0 + wave * RPW + jj * 16 + frow;
-            live[jj] = m < g.M && !(VP_ABLATE(g) & 8);
             const int t = m / g.Win, jx = m - t * g.Win, ii = t % g.Hin, img = t / g.Hin;
-            orow[jj] = (size_t)img * g.Kp * opix + (size_t)(2 * ii + (parity >> 1)) * (2 * g.Win) + 2 * jx + (parity & 1);
+            oimg[jj] = (m < g.M && !(VP_ABLATE(g) & 8)) ? img : -1;
+            opx[jj] = (2 * ii + (parity >> 1)) * (2 * g.Win) + 2 * jx + (parity & 1);
         }
         auto group = [&](const u32x4(&w)[16], int u) {
             f32x4 ah[JW], al[JW];
-            const int nb = u * 16 + fg * 4;
+            int fg_g = fg;
+            asm volatile("" : "+v"(fg_g));
+            const int nb = u * 16 + fg_g * 4;
             const f32x4 b2 = *(const f32x4*)(g.bias2 + nb);   // padded to a multiple of 256 floats at upload
 #pragma unroll
             for (int jj = 0; jj < JW; ++jj) { ah[jj] = f32x4{0.f, 0.f, 0.f, 0.f}; al[jj] = f32x4{0.f, 0.f, 0.f, 0.f}; }
@@ -539,9 +546,12 @@ __global__ __launch_bounds__(C::NT, 2) void gemm_kernel(GemmArgs g) {
 #pragma unroll
             for (int jj = 0; jj < JW; ++jj) {
                 const f32x4 v = ah[jj] + al[jj];
+                int im = oimg[jj], px = opx[jj];
+                asm volatile("" : "+v"(im), "+v"(px));
+                float* orow = g.out2 + ((size_t)im * g.Kp + nb) * opix + px;
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    if (live[jj] && nb + r < g.Kp) g.out2[orow[jj] + (size_t)(nb + r) * opix] = v[r] + b2[r];
+                    if (im >= 0 && nb + r < g.Kp) orow[(size_t)r * opix] = v[r] + b2[r];
             }
         };
         for (int u = 0; u < groups; u += 2) {
@@ -1160,6 +1170,7 @@ static hipError_t launch(const GemmArgs& a, hipStream_t s) {
     static_assert(LDS_BYTES + LN_STAT_BYTES <= 160 * 1024, "LDS");
     if (a.ln_part && (C::PIPE == 2 || C::PIPE == 3 || C::DIRECT)) return hipErrorInvalidValue;   // the prologue merge lives in the generic loop
     if (a.ln_part && C::BM * a.ln_tiles * 8 > C::STAGE_BYTES) return hipErrorInvalidValue;                  // ... and borrows one ring slot
+    if (a.ln_part && (a.ln_tiles & 1)) return hipErrorInvalidValue;   // the block of partial statistics is DMA'd in 16-byte pieces: rows of ln_tiles * 8 bytes must be 16-byte multiples
     static bool attr_done[64] = {};   // the > 64 KiB LDS opt-in is a per-device function attribute
     int dev = 0;
     (void)hipGetDevice(&dev);

@@ -100,6 +100,9 @@ struct vp_ctx {
         // staged download (the group path): the D2H lands in this pinned buffer and vp_infer_wait copies it to the caller's `user_out`,
         // so the submission never blocks on the compute whatever kind of host memory the caller owns
         float* host_kp = nullptr; float* user_out = nullptr; size_t out_bytes = 0;
+        // staged upload (the group path with PAGEABLE caller memory): an asynchronous H2D from pageable memory is host-synchronous (the
+        // runtime stages it and waits), so the crops go through this pinned buffer in pieces -- host memcpy of piece k+1 under the DMA of piece k
+        char* host_in = nullptr; size_t host_in_cap = 0;
     };
     Slot slots[2];
     hipStream_t copy_stream = nullptr;   // H2D of the asynchronous path
@@ -463,9 +466,9 @@ int gemm(vp_ctx* c, int fam, int epi, const uint16_t* A, const uint16_t* W, cons
     if (epi == vp::EPI_BIAS_RESID_LN || epi == vp::EPI_POS_LN) bytes += 8.0 * M * (double)(N / 64);   // partial row statistics
     char desc[192];
     desc[0] = 0;
-    if (c->prof != 0 || c->kernel_desc[fam].empty()) { g.desc = desc; g.desc_cap = (int)sizeof(desc); }   // the launch code names the kernel it resolved to
+    g.desc = desc; g.desc_cap = (int)sizeof(desc);   // the launch code names the kernel it resolved to (one snprintf per GEMM launch: vp_profile_kernel reports the LAST launch)
     LAUNCH(c, fam, flops, bytes, vp::gemm_launch(c->dtype, epi, g, c->stream));
-    if (desc[0]) c->kernel_desc[fam] = desc;
+    if (desc[0] && c->kernel_desc[fam] != desc) c->kernel_desc[fam] = desc;
     return VP_OK;
 }
 
@@ -585,7 +588,15 @@ int run_chunk(vp_ctx* c, const void* d_src, int fmt, int nb, const int32_t* d_wh
     rc = forward_chunk(c, d_src, fmt, nb, false);
     if (!rc) rc = decode_chunk(c, d_wh, d_out, nb);
     e = hipStreamEndCapture(c->stream, &graph);
-    if (rc) { if (graph) hipGraphDestroy(graph); ge->no_graph = true; return rc; }
+    if (rc) {   // a launch failed INSIDE the capture (e.g. a capture-illegal call): nothing has executed -- drop the graph, clear the sticky
+                // error and run the chunk eagerly, now and from now on; an error is reported only if the eager run fails too
+        if (graph) hipGraphDestroy(graph);
+        (void)hipGetLastError();
+        ge->exec = nullptr;
+        ge->no_graph = true;
+        c->err.clear();
+        return eager();
+    }
     if (e == hipSuccess && graph) {
         e = hipGraphInstantiate(&ge->exec, graph, nullptr, nullptr, 0);
         hipGraphDestroy(graph);
@@ -663,10 +674,10 @@ int vp_create(vp_handle* out, const vp_config* cfg) {
     if (const char* f = getenv("VP_FUSE_HEAD")) c->fuse_head = atoi(f) != 0;
     if (const char* f = getenv("VP_FOLD_STATS")) c->graph_max_n_stats = atoi(f);
     if (const char* f = getenv("VP_BLOCKED_QKV")) c->blocked_qkv = atoi(f) != 0;
+    if (const char* f = getenv("VP_GEMM8")) c->gemm8_mask = atoi(f);   // which GEMMs may take the 8-phase kernel (1 fc2, 2 fc1, 4 qkv, 8 proj; 0 = the 2-phase kernels everywhere)
 #ifdef VP_TOOLS   // development switches of the measurement build (tools/)
     if (const char* f = getenv("VP_BLOCKED_HID")) c->blocked_hid = atoi(f) != 0;
     if (const char* f = getenv("VP_ORDER")) c->order_mask = atoi(f);
-    if (const char* f = getenv("VP_GEMM8")) c->gemm8_mask = atoi(f);
     if (const char* f = getenv("VP_G8_STAGGER")) c->g8_stagger = atoi(f);
     if (const char* f = getenv("VP_G8_DEFERRED")) c->g8_deferred = atoi(f) != 0;
     if (const char* t = getenv("VP_ABLATE_FAM")) {   // e.g. "2:64,1:64" = non-temporal stores in the qkv and fc1 epilogues
@@ -833,6 +844,15 @@ void vp_host_free(void* p) { if (p) hipHostFree(p); }
 // stage_out: the D2H targets the slot's own pinned buffer and vp_infer_wait copies it to `out` (the group path: the caller's
 // memory may be pageable, and an asynchronous copy to pageable memory is host-synchronous -- it would hold the submission until the
 // compute is over and serialise the devices of a group)
+// true when `p` is page-locked host memory the runtime knows (hipHostMalloc / vp_host_alloc / hipHostRegister): only such memory is
+// copied asynchronously as it is
+static bool host_ptr_is_pinned(const void* p) {
+    hipPointerAttribute_t a;
+    std::memset(&a, 0, sizeof(a));
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }   // unknown to the runtime = pageable
+    return a.type == hipMemoryTypeHost;
+}
+
 static int submit_impl(vp_handle c, const void* crops, int32_t fmt, int32_t n, const int32_t* org_wh, float* out, int32_t* slot_out, bool stage_out) {
     int rc = check_ready(c, fmt, n, crops, out);
     if (rc) return rc;
@@ -854,7 +874,25 @@ static int submit_impl(vp_handle c, const void* crops, int32_t fmt, int32_t n, c
     if (!sl.done) HIPCHK(c, hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
     if (!sl.out) HIPCHK(c, hipEventCreateWithFlags(&sl.out, hipEventDisableTiming));
     // copy stream: H2D of this call (the slot's previous D2H finished: vp_infer_wait was called on it)
-    HIPCHK(c, hipMemcpyAsync(sl.in, crops, (size_t)n * crop_bytes(fmt), hipMemcpyHostToDevice, c->copy_stream));
+    const size_t in_bytes = (size_t)n * crop_bytes(fmt);
+    if (stage_out && !host_ptr_is_pinned(crops)) {
+        // the group path with pageable caller memory: staged through the slot's pinned buffer in 4 MiB pieces, so that this call never
+        // waits for a device (hipMemcpyAsync from pageable memory held member i + 1's submission behind member i's staging)
+        if (sl.host_in_cap < in_bytes) {
+            if (sl.host_in) { HIPCHK(c, hipStreamSynchronize(c->copy_stream)); hipHostFree(sl.host_in); sl.host_in = nullptr; sl.host_in_cap = 0; }
+            void* q = nullptr;
+            HIPCHK(c, hipHostMalloc(&q, in_bytes, hipHostMallocDefault));
+            sl.host_in = (char*)q; sl.host_in_cap = in_bytes;
+        }
+        const size_t piece = (size_t)4 << 20;
+        for (size_t off = 0; off < in_bytes; off += piece) {
+            const size_t len = in_bytes - off < piece ? in_bytes - off : piece;
+            std::memcpy(sl.host_in + off, (const char*)crops + off, len);
+            HIPCHK(c, hipMemcpyAsync((char*)sl.in + off, sl.host_in + off, len, hipMemcpyHostToDevice, c->copy_stream));
+        }
+    } else {
+        HIPCHK(c, hipMemcpyAsync(sl.in, crops, in_bytes, hipMemcpyHostToDevice, c->copy_stream));
+    }
     if (org_wh) HIPCHK(c, hipMemcpyAsync(sl.wh, org_wh, (size_t)n * 8, hipMemcpyHostToDevice, c->copy_stream));
     HIPCHK(c, hipEventRecord(sl.h2d, c->copy_stream));
     // compute stream: after the upload
@@ -1117,6 +1155,45 @@ int vp_dbg_group_plan(int32_t n, int32_t w, int32_t maxb, int32_t* offs, int32_t
     return e;
 }
 
+// The two-phase schedule of a group call, as ONE function for the real path (group_run) and for the host-only trace
+// (vp_dbg_group_trace): per round of `w` plan entries, phase 1 calls submit(member, off, cnt) for EVERY member with work before phase 2
+// calls wait(member) for any of them.  submit returns 0 or an error code; on an error every member already submitted in this round
+// is waited for (drained) before the error is returned, so no slot of any member stays in flight.
+extern "C++" {
+template <class Submit, class Wait>
+static int group_rounds(const std::vector<int>& offs, const std::vector<int>& cnts, int w, Submit submit, Wait wait) {
+    const int entries = (int)offs.size();
+    for (int e0 = 0; e0 < entries; e0 += w) {
+        std::vector<char> inflight(w, 0);
+        auto drain = [&](int from) { for (int i = from; i < w; ++i) if (inflight[i]) { wait(i); inflight[i] = 0; } };
+        for (int i = 0; i < w; ++i) {                    // phase 1 -- enqueue on every member; nothing here waits for a device
+            if (cnts[e0 + i] <= 0) continue;
+            const int rc = submit(i, offs[e0 + i], cnts[e0 + i]);
+            if (rc) { drain(0); return rc; }
+            inflight[i] = 1;
+        }
+        for (int i = 0; i < w; ++i)                      // phase 2 -- collect
+            if (inflight[i]) {
+                inflight[i] = 0;
+                const int rc = wait(i);
+                if (rc) { drain(i + 1); return rc; }
+            }
+    }
+    return VP_OK;
+}
+}   // extern "C++"
+
+// host-only: the order in which a call of n crops on w members of max_batch maxb submits (+ (member + 1)) and waits (- (member + 1)),
+// with stub members (tests/test_host_logic.py: every submission of a round precedes its first wait)
+int vp_dbg_group_trace(int32_t n, int32_t w, int32_t maxb, int32_t* trace, int32_t cap) {
+    std::vector<int> offs, cnts;
+    if (group_plan(n, w, maxb, offs, cnts) < 0 || cap < 0 || (cap > 0 && !trace)) return -1;
+    int len = 0;
+    auto put = [&](int v) { if (len < cap) trace[len] = v; ++len; };
+    group_rounds(offs, cnts, w, [&](int i, int, int) { put(i + 1); return 0; }, [&](int i) { put(-(i + 1)); return 0; });
+    return len;
+}
+
 static int group_run(vp_group* g, const void* crops, int32_t fmt, int32_t n, const int32_t* org_wh, float* out, float* const* d_all) {
     if (!g || n < 0 || (n > 0 && (!crops || (!out && !d_all)))) return VP_ERR_INVALID;
     const int w = (int)g->h.size();
@@ -1124,39 +1201,37 @@ static int group_run(vp_group* g, const void* crops, int32_t fmt, int32_t n, con
     std::vector<float> scratch;
     if (!out) { scratch.resize((size_t)n * K * 3); out = scratch.data(); }
     std::vector<int> offs, cnts;
-    const int entries = group_plan(n, w, g->h[0]->maxb, offs, cnts);
-    if (entries < 0) return VP_ERR_INVALID;
-    for (int e0 = 0; e0 < entries; e0 += w) {
-        std::vector<int> slot(w, -1);
-        // an error leaves no slot of any member in flight: every submitted shard is waited for before the error is returned
-        auto drain = [&](int from) { for (int i = from; i < w; ++i) if (slot[i] >= 0) { vp_infer_wait(g->h[i], slot[i]); slot[i] = -1; } };
-        // phase 1 -- enqueue on EVERY member: upload, model, decode, download into the member's pinned staging buffer (and the peer
-        // copies of the device-side all-gather).  Nothing here waits for a device, so all members compute concurrently.
-        for (int i = 0; i < w; ++i) {
-            const int off = offs[e0 + i], cnt = cnts[e0 + i];
-            if (cnt <= 0) continue;
-            vp_ctx* c = g->h[i];
-            int rc = submit_impl(c, (const char*)crops + (size_t)off * crop_bytes(fmt), fmt, cnt, org_wh ? org_wh + 2 * (size_t)off : nullptr,
-                                 out + (size_t)off * K * 3, &slot[i], true);
-            if (rc) { g->err = c->err; slot[i] = -1; drain(0); return rc; }
-            if (d_all) {   // all-gather on the device side: this shard's keypoints to every device's copy, peer to peer, on the owner's stream
-                for (int j = 0; j < w; ++j) {
-                    hipError_t e = hipMemcpyPeerAsync(d_all[j] + (size_t)off * K * 3, g->h[j]->cfg.device_id, c->slots[slot[i]].kp,
-                                                      c->cfg.device_id, (size_t)cnt * K * 12, c->stream);
-                    if (e != hipSuccess) { g->err = std::string("hipMemcpyPeerAsync: ") + hipGetErrorString(e); drain(0); return VP_ERR_HIP; }
+    if (group_plan(n, w, g->h[0]->maxb, offs, cnts) < 0) return VP_ERR_INVALID;
+    std::vector<int> slot(w, -1);
+    // phase 1 per member: upload (pinned caller memory as it is, pageable memory through the member's pinned staging buffer), model,
+    // decode, download into the member's pinned staging buffer, and the peer copies of the device-side all-gather -- all enqueued, none
+    // waited for, so the members compute concurrently.  phase 2: wait for the member's download, copy its slice to the caller's buffer.
+    auto submit = [&](int i, int off, int cnt) -> int {
+        vp_ctx* c = g->h[i];
+        int rc = submit_impl(c, (const char*)crops + (size_t)off * crop_bytes(fmt), fmt, cnt, org_wh ? org_wh + 2 * (size_t)off : nullptr,
+                             out + (size_t)off * K * 3, &slot[i], true);
+        if (rc) { g->err = c->err; slot[i] = -1; return rc; }
+        if (d_all) {   // all-gather on the device side: this shard's keypoints to every device's copy, peer to peer, on the owner's stream
+            for (int j = 0; j < w; ++j) {
+                hipError_t e = hipMemcpyPeerAsync(d_all[j] + (size_t)off * K * 3, g->h[j]->cfg.device_id, c->slots[slot[i]].kp,
+                                                  c->cfg.device_id, (size_t)cnt * K * 12, c->stream);
+                if (e != hipSuccess) {
+                    g->err = std::string("hipMemcpyPeerAsync: ") + hipGetErrorString(e);
+                    vp_infer_wait(c, slot[i]); slot[i] = -1;   // this member is not marked in flight yet: collect it here
+                    return VP_ERR_HIP;
                 }
             }
         }
-        // phase 2 -- collect: wait for each member's download, copy its slice to the caller's buffer
-        for (int i = 0; i < w; ++i)
-            if (slot[i] >= 0) {
-                int rc = vp_infer_wait(g->h[i], slot[i]);
-                slot[i] = -1;
-                if (!rc && d_all) rc = vp_synchronize(g->h[i]);
-                if (rc) { g->err = g->h[i]->err; drain(i + 1); return rc; }
-            }
-    }
-    return VP_OK;
+        return VP_OK;
+    };
+    auto wait = [&](int i) -> int {
+        int rc = vp_infer_wait(g->h[i], slot[i]);
+        slot[i] = -1;
+        if (!rc && d_all) rc = vp_synchronize(g->h[i]);
+        if (rc) g->err = g->h[i]->err;
+        return rc;
+    };
+    return group_rounds(offs, cnts, w, submit, wait);
 }
 
 int vp_group_infer(vp_group_handle g, const void* crops, int32_t fmt, int32_t n, const int32_t* org_wh, float* out) {
@@ -1223,7 +1298,7 @@ int vp_destroy(vp_handle c) {
     if (c->stream) hipStreamSynchronize(c->stream);
     for (auto& e : c->evs) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
     for (auto& p : c->ev_pool) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
-    for (auto& sl : c->slots) { if (sl.h2d) hipEventDestroy(sl.h2d); if (sl.done) hipEventDestroy(sl.done); if (sl.out) hipEventDestroy(sl.out); if (sl.host_kp) hipHostFree(sl.host_kp); }
+    for (auto& sl : c->slots) { if (sl.h2d) hipEventDestroy(sl.h2d); if (sl.done) hipEventDestroy(sl.done); if (sl.out) hipEventDestroy(sl.out); if (sl.host_kp) hipHostFree(sl.host_kp); if (sl.host_in) hipHostFree(sl.host_in); }
     if (c->ev_in) hipEventDestroy(c->ev_in);
     if (c->ev_out) hipEventDestroy(c->ev_out);
     for (auto& ge : c->graphs) if (ge.exec) hipGraphExecDestroy(ge.exec);

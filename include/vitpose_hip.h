@@ -151,9 +151,12 @@ VP_API int vp_infer_wait(vp_handle h, int32_t slot);
  * each shard is copied peer to peer (hipMemcpyPeerAsync over the xGMI link of the pair) on its owner's stream -- the
  * all-gather of north_star without a collective library in the C ABI (the one-process-per-GPU Python host uses RCCL:
  * easy_vitpose_amd/parallel.py).  `out` may be NULL there.  cfg->device_id is ignored. */
-/* Concurrency: a call enqueues upload + model + decode + download on EVERY member first (the download lands in a
- * pinned per-member staging buffer, so no member's submission waits for its own compute whatever kind of host memory the
- * caller passed) and only then waits for the members in turn and copies their slices into `out`.
+/* Concurrency: a call enqueues upload + model + decode + download on EVERY member first and only then waits
+ * for the members in turn and copies their slices into `out`.  Neither direction blocks the enqueue on a device: the download lands
+ * in a pinned per-member staging buffer; the upload is asynchronous as it is when `crops` is page-locked memory the runtime knows
+ * (vp_host_alloc / hipHostMalloc / hipHostRegister: checked with hipPointerGetAttributes) and otherwise goes through a pinned
+ * per-member staging buffer in 4 MiB pieces (host memcpy of piece k + 1 under the DMA of piece k).  Pass pinned crops for full overlap:
+ * with pageable memory the calling thread's memcpy (~10 GB/s: ~4 ms per 256 u8 crops, ~15 ms per 256 f32 crops) is what serialises the members.
  * Ordering of vp_group_infer_allgather: the peer copies into d_all[j] run on the OWNER's private stream; nothing orders them
  * against work the caller has in flight on device j, so d_all[*] must be idle (already synchronised) when the call starts;
  * the call returns after every copy has completed (host-synchronised), so consumers need no further ordering.  Pairs without
@@ -263,6 +266,10 @@ VP_API int vp_dbg_gemm_compare(int32_t device_id, int32_t dtype, int32_t epi, in
  * per device (trailing devices short or empty).  Entry e = round * w + device: offs[e], cnts[e].  Returns the number of
  * entries (rounds * w), also when it exceeds `cap` (nothing is written beyond cap); < 0 on bad arguments. */
 VP_API int vp_dbg_group_plan(int32_t n, int32_t w, int32_t maxb, int32_t* offs, int32_t* cnts, int32_t cap);
+/* The two-phase schedule of a group call -- HOST ONLY, stub members: the order in which group_run would submit to (+ (member + 1)) and
+ * wait for (- (member + 1)) its members for n crops on w devices of max_batch maxb.  Within every round all submissions precede the
+ * first wait: no member's enqueue waits for another member's compute.  Returns the trace length (also beyond `cap`); < 0 on bad arguments. */
+VP_API int vp_dbg_group_trace(int32_t n, int32_t w, int32_t maxb, int32_t* trace, int32_t cap);
 /* BASELINE config 5 probe (fp8 is documented tolerance-infeasible; this confirms the CPU emulation the
  * finding rests on, tests/fp8_budget.py, on the hardware): rows of A [M,K] and W [N,K] are quantised on device to OCP e4m3
  * (x / scale[row], v_cvt_pk_fp8_f32) and multiplied through v_mfma_f32_16x16x128_f8f6f4:

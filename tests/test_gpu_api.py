@@ -168,14 +168,21 @@ def test_mid_batch_gemm8_selection_is_bit_identical(monkeypatch, n):
     path must not change by a bit against VP_GEMM8=0."""
     shp, sd, _ = weights('b', 'coco')
     crops = synthetic_crops(n, 41, 'blobs')
-    monkeypatch.setenv('VP_GEMM8', '0')
+    fams = ('gemm_qkv', 'gemm_fc1', 'gemm_fc2')
+    monkeypatch.setenv('VP_GEMM8', '0')           # a PRODUCT-side switch (vp_create): every GEMM on the 2-phase kernels
     eng = VitPoseHip(shp, sd, dtype='fp16', max_batch=n)
     ref_kp, ref_tok = eng.infer(crops), eng.tokens(crops)
+    ref_kernels = {f: eng.profile_kernel(f) for f in fams}
     eng.close()
     monkeypatch.delenv('VP_GEMM8')
     eng = VitPoseHip(shp, sd, dtype='fp16', max_batch=n)
     kp, tok = eng.infer(crops), eng.tokens(crops)
+    kernels = {f: eng.profile_kernel(f) for f in fams}
     eng.close()
+    # the two engines really ran different kernels (ADVICE r3: with the switch compiled out of the product build this test passed vacuously)
+    assert all('gemm8_kernel' not in k and k for k in ref_kernels.values()), ref_kernels
+    assert any('gemm8_kernel' in k for k in kernels.values()), kernels
+    print(f'[{n} crops] VP_GEMM8=0: {ref_kernels}; default: {kernels}')
     assert np.array_equal(tok, ref_tok)
     assert np.array_equal(kp, ref_kp)
 

@@ -1,0 +1,255 @@
+"""GPU: the PRODUCTION kernel set of BASELINE configs[2] / configs[3] / ViTPose-S at the bench batch under assertion (VERDICT r3
+item 1).  The model-level goldens hold 1-8 crops, which resolve to the small-batch tile table; at the batch sizes the BASELINE
+names, other kernels run -- the 8-phase GEMMs at K = 1024 / 1280 / 4096 / 5120, the register-direct residual epilogue at
+N = 1024 / 1280, head dim 80 / 32 attention with many regrouped super-groups, the fused head at K = 133 -- and each of them is
+asserted here:
+
+* whole-batch properties: finite, run-to-run identical, crop i of B == crop i alone, ALL B crops == the `max_batch=8` path bit
+  for bit (different kernels, same accumulation order by construction);
+* the reference's own peaked-checkpoint keypoints (tests/golden/peaked_*.npz) for crops placed INSIDE the big batch:
+  +-0.5 px / 1e-3 on every joint;
+* heatmaps and confidences of further crops of the batch against the fp32 oracle;
+* op level: every production GEMM configuration at the (N, K) of ViTPose-L / -H against fp64 and against each other bit for
+  bit; attention at the full block counts.
+
+Shape contract: /root/reference/easy_ViTPose/configs/ViTPose_common.py:157-195, ViTPose_wholebody.py:4-20.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from cases import peaked_crops
+from easy_vitpose_amd import VitPoseHip
+from easy_vitpose_amd import _capi as capi
+from easy_vitpose_amd.configs import model_shape
+from easy_vitpose_amd.synth import synthetic_crops, synthetic_state_dict
+from helpers import CONF_TOL, KP_TOL_PX, round_to
+from oracle import vitpose_cpu as O
+
+pytestmark = pytest.mark.gpu
+
+HM_MAX_ERR, HM_RMS_ERR = 4e-3, 6e-4     # fp16 budgets of tests/test_gpu_parity.py
+
+
+# expected kernel families per case (substring of vp_profile_kernel): the selection rule of vitpose_api.hip gemm() at these sizes
+CASES = [
+    # variant, dataset, batch, oracle crops, {family: substring}
+    ('h', 'wholebody', 128, 2, {'gemm_qkv': 'gemm8_kernel<F16, 0, G8<256>>', 'gemm_fc1': 'gemm8_kernel<F16, 1, G8<256>>',
+                                 'gemm_fc2': 'gemm8_kernel<F16, 6, G8<256>>'}),
+    ('l', 'coco_25', 64, 2, {'gemm_qkv': 'gemm8_kernel<F16, 0, G8<256>>', 'gemm_fc1': 'gemm8_kernel<F16, 1, G8<256>>'}),
+    ('s', 'coco', 256, 4, {'gemm_fc1': 'gemm8_kernel<F16, 1, G8<256>>'}),
+]
+
+
+@pytest.mark.parametrize('variant,dataset,B,n_oracle,expect', CASES, ids=[f'{c[0]}-{c[1]}-{c[2]}' for c in CASES])
+def test_production_batch_under_assertion(golden_dir, variant, dataset, B, n_oracle, expect):
+    z = np.load(os.path.join(golden_dir, f'peaked_{variant}_{dataset}.npz'))
+    ng = int(z['n'])
+    shp = model_shape(variant, dataset)
+    sd = synthetic_state_dict(shp, 0, peaked=True)
+    crops = synthetic_crops(B, 31, 'noise')
+    crops[B // 2:] = synthetic_crops(B - B // 2, 32, 'blobs')
+    pos = np.linspace(0, B - 1, ng).round().astype(int)          # golden crops spread over the batch, first and last slot included
+    crops[pos] = peaked_crops(ng)
+    eng = VitPoseHip(shp, sd, dtype='fp16', device_id=0, max_batch=B)
+    out = eng.infer(crops)
+    kernels = {f: eng.profile_kernel(f) for f in ('gemm_qkv', 'gemm_proj', 'gemm_fc1', 'gemm_fc2', 'gemm_deconv')}
+    print(f'[{variant}/{dataset} @ {B}] kernels: {kernels}')
+    for fam, sub in expect.items():
+        assert sub in kernels[fam], f'{fam} ran on {kernels[fam]!r}, expected {sub!r}: this test must cover the production kernel'
+    assert out.shape == (B, shp.num_keypoints, 3) and np.isfinite(out).all()
+    assert np.array_equal(eng.infer(crops), out), 'run-to-run difference at the production batch'
+    idx = sorted({0, 1, B // 3, B // 2, B - 2, B - 1})
+    assert np.array_equal(np.concatenate([eng.infer(crops[i:i + 1]) for i in idx]), out[idx]), 'crop i of the batch != crop i alone'
+    oidx = [int(i) for i in np.linspace(3, B - 4, n_oracle).round()]
+    hm = eng.heatmaps(crops[oidx])
+    eng.close()
+    # every crop against the small-batch path (64x64 / 128x128 tiles, one tile per workgroup, consumer-merged statistics)
+    small = VitPoseHip(shp, sd, dtype='fp16', device_id=0, max_batch=8)
+    small_out = small.infer(crops)
+    small.close()
+    assert np.array_equal(small_out, out), f'{(small_out != out).any(axis=(1, 2)).sum()} of {B} crops differ from the max_batch=8 path'
+    # the reference's own keypoints for the golden crops inside the batch: every joint
+    ref = z['keypoints']
+    dpx = np.abs(out[pos][..., :2] - ref[..., :2]).max(-1)
+    dcf = np.abs(out[pos][..., 2] - ref[..., 2])
+    print(f'[{variant}/{dataset} @ {B}, peaked golden inside the batch] {dpx.size} joints: coordinate max err {dpx.max():.4f} px, '
+          f'confidence max err {dcf.max():.3e}')
+    assert dpx.max() < KP_TOL_PX and dcf.max() < CONF_TOL
+    # further crops of the batch against the fp32 oracle (heatmaps of the peaked checkpoint: all joints)
+    sdt = O.to_torch_state_dict(sd)
+    x = np.concatenate([O.pre_img(c)[0] for c in crops[oidx]])
+    ref_hm = np.concatenate([O.model_forward(sdt, x[i:i + 1], shp.depth, shp.num_heads) for i in range(len(oidx))])
+    err = np.abs(hm - ref_hm)
+    ref_kp = O.decode_per_crop(ref_hm)
+    d2 = np.abs(out[oidx][..., :2] - ref_kp[..., :2]).max(-1)
+    c2 = np.abs(out[oidx][..., 2] - ref_kp[..., 2])
+    print(f'[{variant}/{dataset} @ {B}, oracle on crops {oidx}] heatmap max err {err.max():.3e} rms {np.sqrt((err ** 2).mean()):.3e}; '
+          f'{d2.size} joints: coordinate max err {d2.max():.4f} px, confidence max err {c2.max():.3e}')
+    assert err.max() < HM_MAX_ERR and np.sqrt((err ** 2).mean()) < HM_RMS_ERR
+    assert d2.max() < KP_TOL_PX and c2.max() < CONF_TOL
+
+
+# ------------------------------------------------------------------ op level: GEMM configurations at D = 1024 / 1280
+M_ROWS = 192 * 16          # 3072 = 12 x 256 token rows
+
+
+def _case(epi, variant, flags, A, W, bias, aux=None, rowstat=None, ln_s=None, group_m=8, want_stats=False):
+    lib = capi.load_library()
+    m, k = A.shape
+    n = W.shape[0]
+    out = np.empty((m, n), dtype=np.float32)
+    stats = np.empty((m, n // 64, 2), dtype=np.float32) if want_stats else None
+    keep = [np.ascontiguousarray(a, dtype=np.float32) if a is not None else None for a in (A, W, bias, aux, rowstat, ln_s)]
+    rc = lib.vp_dbg_gemm_case(0, capi.VP_DTYPE_F16, epi, variant, group_m, flags, m, n, k,
+                              *[None if a is None else a.ctypes.data for a in keep], out.ctypes.data,
+                              None if stats is None else stats.ctypes.data)
+    assert rc == 0, capi.last_error()
+    return (out, stats) if want_stats else out
+
+
+def _gelu(x):
+    from scipy.special import erf
+    return 0.5 * x * (1.0 + erf(x / np.sqrt(2.0)))
+
+
+@pytest.mark.parametrize('name,N,K,epi,flags', [('qkv-L', 3072, 1024, 0, 0), ('fc1-L', 4096, 1024, 1, 2),
+                                                ('qkv-H', 3840, 1280, 0, 0), ('fc1-H', 5120, 1280, 1, 2)])
+def test_wide_gemm_configurations_large_models(name, N, K, epi, flags):
+    """LayerNorm-consumer fold + bias (+ GELU + blocked output) at the (N, K) of ViTPose-L / -H: fp64 reference, then bit identity
+    of the 8-phase kernel with the 2-phase configurations."""
+    rng = np.random.default_rng(N + K)
+    M = M_ROWS
+    A = round_to(rng.standard_normal((M, K)).astype(np.float32), 'fp16')
+    W = round_to((rng.standard_normal((N, K)) * 0.04).astype(np.float32), 'fp16')
+    bias = (rng.standard_normal(N) * 0.1).astype(np.float32)
+    rowstat = np.stack([rng.standard_normal(M) * 0.2, 1.0 + 0.3 * rng.random(M)], 1).astype(np.float32)
+    ln_s = W.astype(np.float64).sum(1).astype(np.float32)
+    acc = (torch.from_numpy(A).double() @ torch.from_numpy(W).double().T).numpy()
+    ref = (acc - rowstat[:, :1].astype(np.float64) * ln_s.astype(np.float64)) * rowstat[:, 1:].astype(np.float64) + bias
+    if epi == 1:
+        ref = _gelu(ref)
+    outs = {}
+    for label, variant, fl in [('cfg9', 9, 0), ('cfg8', 8, 0), ('cfg8 persistent', 8, 1), ('gemm8 256x256', 16, 0)]:
+        o = _case(epi, variant, flags | fl, A, W, bias, rowstat=rowstat, ln_s=ln_s)
+        err = np.abs(o - ref)
+        tol = 2.0 ** -10 * np.abs(ref) + 3e-4
+        assert (err <= tol).all(), f'{name} {label}: max err {err.max():.3e} (worst ratio {(err / tol).max():.2f})'
+        outs[label] = o
+    for label, o in outs.items():
+        assert np.array_equal(o, outs['cfg9']), f'{name}: {label} differs from cfg9 in {(o != outs["cfg9"]).sum()} elements'
+
+
+@pytest.mark.parametrize('name,N,K,flags', [('proj-L', 1024, 1024, 0), ('fc2-L', 1024, 4096, 4 | 8), ('proj-H', 1280, 1280, 0),
+                                            ('fc2-H', 1280, 5120, 4 | 8)])
+def test_residual_gemm_configurations_large_models(name, N, K, flags):
+    """bias + two-plane residual + LayerNorm row statistics at N = 1024 / 1280: the 8-phase kernel takes the residual epilogue
+    straight from registers there (256 x 256 tiles; 192 does not divide N).  fp64 reference for planes and statistics, bit
+    identity with the LDS-staged epilogues of the 2-phase kernels."""
+    rng = np.random.default_rng(N * 3 + K)
+    M = M_ROWS
+    A = round_to((rng.standard_normal((M, K)) * (1.0 if K == N else 0.5)).astype(np.float32), 'fp16')
+    W = round_to((rng.standard_normal((N, K)) * 0.03).astype(np.float32), 'fp16')
+    bias = (rng.standard_normal(N) * 0.1).astype(np.float32)
+    resid = (rng.standard_normal((M, N)) * 2.0).astype(np.float32)
+    hi = round_to(resid, 'fp16')
+    x0 = hi.astype(np.float64) + round_to(resid - hi, 'fp16').astype(np.float64)
+    ref = (torch.from_numpy(A).double() @ torch.from_numpy(W).double().T).numpy() + bias + x0
+    outs = {}
+    for label, variant in [('cfg11', 11), ('cfg9', 9), ('gemm8 256x256 register epilogue', 16)]:
+        o, st = _case(6, variant, flags, A, W, bias, aux=resid, want_stats=True, group_m=0 if variant < 16 else 2)
+        assert np.abs(o - ref).max() < 2e-5 * max(1.0, np.abs(ref).max()), f'{name} {label}: planes off by {np.abs(o - ref).max():.3e}'
+        g = o.astype(np.float64).reshape(M, N // 64, 64)
+        assert np.abs(st[..., 0] - g.sum(-1)).max() < 2e-3, f'{name} {label}: granule sums'
+        m2 = ((g - g.mean(-1, keepdims=True)) ** 2).sum(-1)
+        assert np.abs(st[..., 1] - m2).max() < 2e-3 * max(1.0, m2.max()), f'{name} {label}: granule M2'
+        outs[label] = (o, st)
+    bo, bs = outs['cfg11']
+    for label, (o, st) in outs.items():
+        assert np.array_equal(o, bo) and np.array_equal(st, bs), f'{name}: {label} differs from cfg11'
+
+
+# ------------------------------------------------------------------ op level: attention at the production block counts
+@pytest.mark.parametrize('B,D,heads', [(128, 1280, 16), (256, 384, 12), (256, 768, 12)])
+def test_attention_at_production_block_counts(B, D, heads):
+    """2048 / 3072 workgroups: head dim 80 and 32 walk the regrouped block order (four consecutive (crop, head) ids per XCD in
+    super-groups of 32, attention.hip) over 64 / 96 super-groups; every output row against an fp32 torch reference, and crops
+    of the big launch against the same crops launched alone (a (crop, head) workgroup must not depend on where it runs)."""
+    hd = D // heads
+    rng = np.random.default_rng(B + D)
+    qkv = rng.standard_normal((B * 192, 3 * D), dtype=np.float32)
+    qkv[:, :D] *= 1.5
+    qkv = round_to(qkv, 'fp16')
+    out = np.empty((B * 192, D), np.float32)
+    lib = capi.load_library()
+    capi.check(lib.vp_dbg_attention(0, capi.VP_DTYPE_F16, B, D, heads, qkv.ctypes.data, out.ctypes.data))
+    worst = 0.0
+    for b0 in range(0, B, 32):
+        t = torch.from_numpy(qkv[b0 * 192:(b0 + 32) * 192]).double().reshape(32, 192, 3, heads, hd).permute(2, 0, 3, 1, 4)
+        ref = (((t[0] * hd ** -0.5) @ t[1].transpose(-2, -1)).softmax(-1) @ t[2]).transpose(1, 2).reshape(32 * 192, D).numpy()
+        err = np.abs(out[b0 * 192:(b0 + 32) * 192] - ref).max() / np.abs(ref).max()
+        worst = max(worst, float(err))
+    assert worst <= 3 * 2.0 ** -11, f'attention B={B} D={D}: relative max err {worst:.3e}'
+    for b in (0, B // 2 + 1, B - 1):
+        one = np.empty((192, D), np.float32)
+        sl = np.ascontiguousarray(qkv[b * 192:(b + 1) * 192])
+        capi.check(lib.vp_dbg_attention(0, capi.VP_DTYPE_F16, 1, D, heads, sl.ctypes.data, one.ctypes.data))
+        assert np.array_equal(one, out[b * 192:(b + 1) * 192]), f'crop {b} of {B} differs from the same crop launched alone'
+
+
+# ------------------------------------------------------------------ noise-map confidence statistic, tightened
+def test_noise_map_confidence_statistic_vitpose_h():
+    """Random-weight heatmaps are full-scale noise (std 0.3, maxima ~1): with 16-bit operands the error at the arg-max is
+    ~N(0, 3.3e-4) on the 32-block model, so 1e-3 is a 3-sigma event per joint and `every joint < 1e-3` is not a property of the
+    kernels but of the sample size.  What IS asserted, over 64 crops x 133 joints = 8512 joints of ViTPose-H / wholebody: the
+    maximum, the 1e-3 quantile and the rms -- with the histogram tail on record."""
+    from helpers import oracle_heatmaps, weights
+    n = 64
+    crops = synthetic_crops(n, 77, 'noise')
+    crops[:16] = synthetic_crops(16, 78, 'blobs')
+    shp, sd, _ = weights('h', 'wholebody')
+    eng = VitPoseHip(shp, sd, dtype='fp16', device_id=0, max_batch=n)
+    kp = eng.infer(crops)
+    eng.close()
+    ref_hm = oracle_heatmaps('h', 'wholebody', crops, chunk=4)
+    ref = O.decode_per_crop(ref_hm)
+    cerr = np.abs(kp[..., 2] - ref[..., 2]).ravel()
+    edges = [0, 2.5e-4, 5e-4, 7.5e-4, 1e-3, 1.25e-3, 1.5e-3, np.inf]
+    hist = np.histogram(cerr, bins=edges)[0]
+    rms = float(np.sqrt((cerr ** 2).mean()))
+    print(f'[h/wholebody noise maps] {cerr.size} joints: max {cerr.max():.3e}, rms {rms:.3e}, within 1e-3: {(cerr < 1e-3).mean():.5f}; '
+          f'histogram over {edges}: {hist.tolist()}')
+    assert cerr.size >= 8500
+    assert cerr.max() < 1.5e-3
+    assert (cerr < CONF_TOL).mean() >= 0.995
+    assert rms < 3.5e-4
+
+
+# ------------------------------------------------------------------ a real checkpoint, when one is present
+def test_real_checkpoint_when_present():
+    """VITPOSE_CKPT=/path/vitpose-b-coco.pth (the files models/download.sh fetches; none exist offline): the first test a user with
+    real weights runs.  Every joint of 16 blob crops within +-0.5 px / 1e-3 of the fp32 oracle.  Optional: VITPOSE_CKPT_MODEL (s/b/l/h,
+    default from the file name), VITPOSE_CKPT_DATASET (default from the file name, like the reference's infer_dataset_by_path)."""
+    path = os.environ.get('VITPOSE_CKPT')
+    if not path:
+        pytest.skip('VITPOSE_CKPT not set (no real checkpoint offline)')
+    assert os.path.exists(path), path
+    from easy_vitpose_amd.configs import infer_dataset_by_path, infer_variant_from_state_dict
+    ckpt = torch.load(path, map_location='cpu', weights_only=True)            # as the reference does, inference.py:162-166
+    sd = ckpt['state_dict'] if 'state_dict' in ckpt else ckpt
+    name = os.path.basename(path).lower()
+    variant = os.environ.get('VITPOSE_CKPT_MODEL') or infer_variant_from_state_dict(sd)
+    dataset = os.environ.get('VITPOSE_CKPT_DATASET') or infer_dataset_by_path(path)
+    shp = model_shape(variant, dataset)
+    crops = synthetic_crops(16, 5, 'blobs')
+    eng = VitPoseHip(shp, sd, dtype='fp16', device_id=0, max_batch=16)
+    kp = eng.infer(crops)
+    eng.close()
+    sdt = {k: v.float() for k, v in sd.items() if not k.endswith('num_batches_tracked')}
+    ref = np.concatenate([O.inference_torch(sdt, shp.depth, shp.num_heads, c) for c in crops])
+    dpx = np.abs(kp[..., :2] - ref[..., :2]).max(-1)
+    dcf = np.abs(kp[..., 2] - ref[..., 2])
+    print(f'[real checkpoint {name}] {dpx.size} joints: coordinate max err {dpx.max():.4f} px, confidence max err {dcf.max():.3e}')
+    assert dpx.max() < KP_TOL_PX and dcf.max() < CONF_TOL

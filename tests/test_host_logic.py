@@ -198,6 +198,35 @@ def test_group_sharding_plan(n, w, maxb):
     assert lib.vp_dbg_group_plan(-1, w, maxb, None, None, 0) < 0 and lib.vp_dbg_group_plan(n, 0, maxb, None, None, 0) < 0
 
 
+@pytest.mark.parametrize('n,w,maxb', [(64, 8, 8), (513, 8, 64), (7, 8, 64), (2048, 8, 256), (5, 2, 1), (1, 8, 8)])
+def test_group_call_enqueues_every_member_before_it_waits_for_any(n, w, maxb):
+    """The two-phase schedule of vp_group_infer (vitpose_api.hip group_rounds, the function group_run executes) with stub members,
+    host only: inside every round ALL submissions precede the first wait, each member that got work is waited for exactly once, in
+    member order, and the submissions of round r + 1 start only after round r has been collected (the members' two slots are then
+    free again).  Phase 1 of the real path contains no wait either: downloads land in pinned staging, uploads are asynchronous from
+    pinned caller memory or staged in pieces."""
+    lib = capi.load_library()
+    need = lib.vp_dbg_group_trace(n, w, maxb, None, 0)
+    plan_n = lib.vp_dbg_group_plan(n, w, maxb, None, None, 0)
+    cnts = (C.c_int32 * max(plan_n, 1))()
+    offs = (C.c_int32 * max(plan_n, 1))()
+    lib.vp_dbg_group_plan(n, w, maxb, offs, cnts, plan_n)
+    working = sum(1 for e in range(plan_n) if cnts[e] > 0)
+    assert need == 2 * working
+    tr = (C.c_int32 * max(need, 1))()
+    assert lib.vp_dbg_group_trace(n, w, maxb, tr, need) == need
+    tr = list(tr)[:need]
+    pos = 0
+    for r in range(plan_n // w):
+        members = [i + 1 for i in range(w) if cnts[r * w + i] > 0]
+        k = len(members)
+        assert tr[pos:pos + k] == members, f'round {r}: submissions {tr[pos:pos + k]}'           # phase 1: every member, no wait in between
+        assert tr[pos + k:pos + 2 * k] == [-m for m in members], f'round {r}: waits {tr[pos + k:pos + 2 * k]}'   # phase 2
+        pos += 2 * k
+    assert pos == need
+    assert lib.vp_dbg_group_trace(-1, w, maxb, None, 0) < 0
+
+
 def test_bad_config_is_rejected_before_touching_a_device():
     lib = capi.load_library()
     h = C.c_void_p()

@@ -68,34 +68,7 @@ def test_sharded_equals_single_process(n, world):
 
 
 # ------------------------------------------------------------------ bench.py's own multi-rank code path, with a fake engine
-class FakeEngine:
-    """What bench.Harness / bench.strong_scaling_config4 need from VitPoseHip: infer_device(crops, out, sync), synchronize(),
-    close() -- on CPU tensors; 'keypoints' are a deterministic function of each crop, so sharded == unsharded is checkable."""
-    K = 5
-
-    def __init__(self):
-        self.calls = 0
-
-    @staticmethod
-    def expected(crops: torch.Tensor) -> torch.Tensor:
-        s = crops.reshape(len(crops), -1).double().sum(1)
-        base = torch.arange(FakeEngine.K * 3, dtype=torch.float64).reshape(1, FakeEngine.K, 3)
-        return (base + s.reshape(-1, 1, 1) * 1e-3).float()
-
-    def infer_device(self, d_crops, d_out, sync=True):
-        self.calls += 1
-        d_out.copy_(self.expected(d_crops))
-        return d_out
-
-    def synchronize(self):
-        pass
-
-    def close(self):
-        pass
-
-
-def _frame_crops(n):
-    return torch.from_numpy(np.random.default_rng(9).integers(0, 255, size=(n, 6, 4, 3)).astype(np.uint8))
+from fake_bench_engine import FakeEngine, frame_crops as _frame_crops   # noqa: E402  (shared with the VP_BENCH_ENGINE hook of bench.main)
 
 
 def _bench_worker(rank, world, port, n_frame, q):
@@ -152,3 +125,29 @@ def test_bench_multi_rank_code_path_with_fake_engine(n_frame):
         assert np.array_equal(weak, weak_ref), f'rank {rank}: weak-scaling all-gather'
         assert kp.shape == (n_frame, FakeEngine.K, 3) and np.array_equal(kp, frame_ref), f'rank {rank}: strong-scaled frame'
         assert per == -(-n_frame // world) and len(per_rank_ms) == world
+
+
+def test_bench_launches_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` with WORLD_SIZE unset -- the form the driver uses for N = 1 -- must spawn its two ranks itself
+    (torch.distributed.run on 127.0.0.1) and still print exactly ONE JSON line on stdout, from rank 0 (it
+    used to die on an assert).  The ranks run bench.main() end to end over gloo with the fake engine (VP_BENCH_ENGINE hook): argument
+    hand-through, process-group set-up, weak-scaling Harness, the strong-scaled frame, the JSON assembly."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    env['VP_BENCH_ENGINE'] = 'fake_bench_engine:make'
+    env['PYTHONPATH'] = os.path.join(root, 'tests') + os.pathsep + root + os.pathsep + env.get('PYTHONPATH', '')
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1'],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, f'stdout must hold exactly one JSON line, got {len(lines)}: {r.stdout[:500]}'
+    j = json.loads(lines[0])
+    assert j['n_gpus'] == 2 and j['steps'] == 3 and j['warmup'] == 1 and j['scaling'] == 'weak'
+    assert j['config']['global_batch'] == 2 * 3 and len(j['per_rank_ms_per_step']) == 2 and j['allgather_ms'] > 0
+    assert j['value'] > 0 and j['cpu_baseline'] is None
+    sc = j['strong_scaling_config4']
+    assert sc['scaling'] == 'strong' and sc['crops_per_rank'] == 4 and len(sc['per_rank_ms_per_frame']) == 2
+    assert 'launching' in r.stderr      # the launcher path ran (not an externally provided WORLD_SIZE)
