@@ -28,7 +28,7 @@ LIB = os.path.join(LIBDIR, 'libvitpose_hip.so')
 TOOLS_LIB = os.path.join(LIBDIR, 'libvitpose_hip_tools.so')
 SOURCES = ['gemm.hip', 'gemm8.hip', 'attention.hip', 'elementwise.hip', 'decode.hip', 'fp8_probe.hip', 'vitpose_api.hip']
 TOOLS_SOURCES = SOURCES + ['gemm8d.hip']
-HEADERS = ['common.h', 'kernels.h', 'gemm8_common.h', os.path.join('..', '..', 'include', 'vitpose_hip.h'),
+HEADERS = ['common.h', 'kernels.h', 'gemm8_common.h', 'mx8.h', os.path.join('..', '..', 'include', 'vitpose_hip.h'),
            os.path.join('..', '..', 'include', 'vitpose_hip_tools.h')]
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-fvisibility=hidden',
          '-ffp-contract=fast', '-Wno-unused-result']

@@ -110,6 +110,11 @@ hipError_t ln_finalize_launch(const float* partials, float* rowstat, int M, int 
 hipError_t fp8_probe_launch(const float* dA, const float* dW, const float* dAs, const float* dWs, uint8_t* dA8, uint8_t* dW8, float* dOut,
                             int M, int N, int K, hipStream_t s);
 
+// MX probe: rows of A -> MXFP8 (e4m3 + one E8M0 scale per 32 k, layouts of mx8.h), W -> e4m3 per-row scale; product through the block-scaled
+// v_mfma_scale_f32_16x16x128_f8f6f4 with the operand roles and the packed scale dwords of the fp8 mode's GEMM.  M % 64 == 0, N % 16 == 0, K % 128 == 0
+hipError_t mx_probe_launch(const float* dA, const float* dW, const float* dWs, uint8_t* dA8, uint8_t* dAs, uint8_t* dW8, float* dOut,
+                           int M, int N, int K, hipStream_t s);
+
 // calibration micro-benchmarks (tools/): kind 0/1 = MFMA 16x16x32 / 32x32x16 f16 TFLOP/s, 2 = float4 copy TB/s
 hipError_t peak_bench(int kind, double* result);
 

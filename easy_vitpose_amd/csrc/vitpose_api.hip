@@ -16,6 +16,7 @@
 #include "../../include/vitpose_hip_tools.h"
 #endif
 #include "kernels.h"
+#include "mx8.h"
 
 namespace {
 
@@ -1847,6 +1848,37 @@ VP_API int vp_dbg_fp8_gemm(int32_t device, int32_t M, int32_t N, int32_t K, cons
     if (e == hipSuccess && w_codes) e = hipMemcpy(w_codes, dW8, (size_t)N * K, hipMemcpyDeviceToHost);
     if (e != hipSuccess) rc = fail(c, VP_ERR_HIP, std::string("fp8 probe: ") + hipGetErrorString(e));
     return dbg_finish(c, rc);
+}
+
+// MX probe (round 4): A -> MXFP8 on device (mx8.h layouts), W -> e4m3 with the per-row scale given; out = block-scaled MFMA product.
+// a_codes [M*K] (blocked layout), a_scales [M*K/32] (packed dword layout), w_codes [N*K] may be NULL.
+VP_API int vp_dbg_mx_gemm(int32_t device, int32_t M, int32_t N, int32_t K, const float* A, const float* W, const float* w_scale, float* out,
+                          uint8_t* a_codes, uint8_t* a_scales, uint8_t* w_codes) {
+    if (M <= 0 || N <= 0 || K <= 0 || M % 64 || N % 16 || K % 128 || !A || !W || !w_scale || !out) return fail(nullptr, VP_ERR_INVALID, "bad mx probe shape");
+    vp_ctx* c = dbg_ctx(device, VP_DTYPE_F16);
+    if (!c) return VP_ERR_HIP;
+    float *dA, *dW, *dWs, *dO;
+    uint8_t *dA8, *dAs, *dW8;
+    int rc;
+    if ((rc = upload_f32(c, &dA, A, (size_t)M * K)) || (rc = upload_f32(c, &dW, W, (size_t)N * K)) || (rc = upload_f32(c, &dWs, w_scale, N)) ||
+        (rc = dalloc(c, &dO, (size_t)M * N)) || (rc = dalloc(c, &dA8, (size_t)M * K)) || (rc = dalloc(c, &dAs, (size_t)M * K / 32)) ||
+        (rc = dalloc(c, &dW8, (size_t)N * K)))
+        return dbg_finish(c, rc);
+    hipError_t e = vp::mx_probe_launch(dA, dW, dWs, dA8, dAs, dW8, dO, M, N, K, nullptr);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipMemcpy(out, dO, (size_t)M * N * 4, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && a_codes) e = hipMemcpy(a_codes, dA8, (size_t)M * K, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && a_scales) e = hipMemcpy(a_scales, dAs, (size_t)M * K / 32, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && w_codes) e = hipMemcpy(w_codes, dW8, (size_t)N * K, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) rc = fail(c, VP_ERR_HIP, std::string("mx probe: ") + hipGetErrorString(e));
+    return dbg_finish(c, rc);
+}
+
+// host-only: fp32 -> OCP e4m3 codes with the library's own converter (the one the weight packer of the fp8 mode uses)
+VP_API int vp_dbg_host_e4m3(const float* in, uint8_t* out, int64_t n) {
+    if (!in || !out || n < 0) return VP_ERR_INVALID;
+    for (int64_t i = 0; i < n; ++i) out[i] = vp_host_e4m3(in[i]);
+    return VP_OK;
 }
 
 // Calibration: kind 0/1 = MFMA-only loop (16x16x32 / 32x32x16 f16) in TFLOP/s, 2 = float4 copy in TB/s (read+write).

@@ -277,6 +277,15 @@ VP_API int vp_dbg_group_trace(int32_t n, int32_t w, int32_t maxb, int32_t* trace
  * M, N multiples of 16, K a multiple of 128. */
 VP_API int vp_dbg_fp8_gemm(int32_t device_id, int32_t M, int32_t N, int32_t K, const float* A, const float* a_scale, const float* W,
                            const float* w_scale, float* out, uint8_t* a_codes, uint8_t* w_codes);
+/* MX probe (the opt-in fp8 mode's operand format, csrc/mx8.h): rows of A [M,K] are quantised on device to MXFP8 -- OCP e4m3 codes with
+ * one E8M0 power-of-two scale per block of 32 consecutive k -- W [N,K] to e4m3 with the given per-row scale, and multiplied through the
+ * BLOCK-SCALED v_mfma_scale_f32_16x16x128_f8f6f4 with the operand roles and packed scale dwords of the production GEMM.  Returns the
+ * product and (optionally) the codes / scale bytes in the library's layouts so that a test can restate the arithmetic exactly.
+ * M % 64 == 0, N % 16 == 0, K % 128 == 0. */
+VP_API int vp_dbg_mx_gemm(int32_t device_id, int32_t M, int32_t N, int32_t K, const float* A, const float* W, const float* w_scale, float* out,
+                          uint8_t* a_codes, uint8_t* a_scales, uint8_t* w_codes);
+/* HOST ONLY: fp32 -> OCP e4m3 codes with the converter the fp8 weight packer uses (round to nearest even, saturating at 448) */
+VP_API int vp_dbg_host_e4m3(const float* in, uint8_t* out, int64_t n);
 /* calibration of the box: kind 0/1 = MFMA-only loop 16x16x32 / 32x32x16 f16 (TFLOP/s), 2 = float4 copy (TB/s) */
 VP_API int vp_dbg_peak(int32_t device_id, int32_t kind, double* result);
 

@@ -196,3 +196,66 @@ def test_fp8_probe_confirms_the_emulation():
     rel16 = np.sqrt((((round_to(yn[normal], 'fp16').astype(np.float64) @ round_to(Wn, 'fp16').astype(np.float64).T) - full[normal]) ** 2).mean()) / full[normal].std()
     print(f'[fp8 probe] qkv GEMM {M}x{N}x{K}: e4m3 operand error {rel8:.3e} of the output scale, fp16 operands {rel16:.3e}')
     assert 5e-3 < rel8 < 6e-2 and rel16 < 1e-3
+
+
+def _mx_layout(M, K):
+    """index arrays restating csrc/mx8.h: byte offset of code (m, k) in the blocked layout, of scale byte (m, kb) in the packed dwords"""
+    m = np.arange(M)[:, None]
+    k = np.arange(K)[None, :]
+    code_off = (((m >> 6) * (K >> 7) + (k >> 7)) << 13) + ((m & 63) << 7) + (k & 127)
+    kb = np.arange(K // 32)[None, :]
+    scale_off = (((m >> 6) * (K >> 5) + kb) << 6) + ((m & 15) << 2) + ((m >> 4) & 3)
+    return code_off, scale_off
+
+
+def test_mx_probe_block_scaled_mfma():
+    """The operand format of the opt-in fp8 mode (csrc/mx8.h) on the instruction it is built for: rows quantised on device to MXFP8
+    (e4m3 codes, one E8M0 scale per 32 k) and multiplied through the BLOCK-SCALED v_mfma_scale_f32_16x16x128_f8f6f4 with the
+    production operand roles (weights = A operand with scale 1.0, activations = B operand, the four 16-row fragments' scale bytes
+    packed in one dword per lane and selected by op_sel).  Checked: the scale byte of every block (amax in [128, 256) after scaling),
+    the codes bit for bit against torch.float8_e4m3fn of the scaled values, and the product against fp64 arithmetic on exactly
+    those codes and scales -- i.e. which lane's scale applies to which block, and what op_sel selects."""
+    F8 = torch.float8_e4m3fn
+    M, N, K = 192, 48, 384
+    rng = np.random.default_rng(11)
+    A = rng.standard_normal((M, K)).astype(np.float32)
+    blk = np.exp2(rng.integers(-12, 9, size=(M, K // 32))).astype(np.float32)          # every block in its own binade: 2^-12 .. 2^8
+    A *= np.repeat(blk, 32, axis=1)
+    A[7, 64:96] = 0.0                                                                   # an all-zero block
+    A[9, 40] = 3.0e4                                                                    # an outlier inside a block of small values
+    W = (rng.standard_normal((N, K)) * 0.05).astype(np.float32)
+    W[:, 5] += 0.3 * (np.arange(N) % 4)                                                 # asymmetric
+    ws = (np.abs(W).max(1) / 448.0).astype(np.float32)
+    out = np.empty((M, N), np.float32)
+    ac = np.empty(M * K, np.uint8); asc = np.empty(M * K // 32, np.uint8); wc = np.empty((N, K), np.uint8)
+    lib = capi.load_library()
+    capi.check(lib.vp_dbg_mx_gemm(0, M, N, K, _ptr(A), _ptr(W), _ptr(ws), _ptr(out), _ptr(ac), _ptr(asc), _ptr(wc)))
+    code_off, scale_off = _mx_layout(M, K)
+    codes, E = ac[code_off], asc[scale_off].astype(np.int32)
+    amax = np.abs(A).reshape(M, K // 32, 32).max(-1)
+    ex = (amax.view(np.uint32) >> 23) & 0xff
+    assert np.array_equal(E, np.where(ex > 7, ex - 7, 0)), 'E8M0 scale bytes'
+    inv = np.exp2(127.0 - E).astype(np.float32)
+    scaled = A * np.repeat(inv, 32, axis=1)
+    nz = amax > 0
+    assert (np.abs(scaled).reshape(M, K // 32, 32).max(-1)[nz] >= 128).all() and np.abs(scaled).max() < 256
+    ref_codes = torch.from_numpy(scaled).to(F8).view(torch.uint8).numpy()
+    assert np.array_equal(codes, ref_codes), f'{(codes != ref_codes).sum()} activation codes differ from torch.float8_e4m3fn'
+    ref_w = (torch.from_numpy(W) / torch.from_numpy(ws)[:, None]).to(F8)
+    assert np.array_equal(wc, ref_w.view(torch.uint8).numpy())
+    a_deq = torch.from_numpy(codes.copy()).view(F8).double().numpy() * np.repeat(np.exp2(E - 127.0), 32, axis=1)
+    w_deq = ref_w.double().numpy() * ws[:, None].astype(np.float64)
+    exact = a_deq @ w_deq.T
+    scale = np.abs(a_deq) @ np.abs(w_deq).T
+    rel = np.abs(out - exact) / scale
+    print(f'[mx probe] block-scaled product vs fp64 of the same codes and scales, relative to sum|a||w|: max {rel.max():.3e} (row 9, one outlier: {rel[9].max():.3e})')
+    ok = np.ones(M, bool); ok[9] = False
+    im, inn = np.unravel_index(np.argmax(rel), rel.shape)
+    print(f'[mx probe] worst element ({im}, {inn}): got {out[im, inn]:.6g} exact {exact[im, inn]:.6g}; per-row max of rows 0-11: {np.array2string(rel[:12].max(1), precision=2)}; '
+          f'rows with rel > 1e-4: {np.nonzero(rel.max(1) > 1e-4)[0].tolist()[:20]}')
+    assert rel[ok].max() < 1e-4 and rel[9].max() < 1e-3          # blocks 20 binades apart in one row: the instruction aligns products to the largest
+    # a wrong lane <-> block or op_sel <-> fragment assignment would be off by powers of two, not by 1e-4
+    full = A.astype(np.float64) @ W.astype(np.float64).T
+    qerr = np.sqrt(((out - full)[ok] ** 2).mean()) / full[ok].std()
+    print(f'[mx probe] MXFP8 operand error of this product: {qerr:.3e} of the output scale')
+    assert qerr < 6e-2

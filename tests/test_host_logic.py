@@ -463,3 +463,32 @@ def test_tools_and_bench_scripts_compile():
     assert len(files) > 20
     for f in files:
         ast.parse(open(f).read(), filename=f)
+
+
+def test_host_e4m3_converter_matches_torch():
+    """The fp8 mode's weight packer rounds on the host (csrc/mx8.h vp_host_e4m3): OCP e4m3fn, round to nearest even, subnormals,
+    saturating at 448 -- bit for bit torch.float8_e4m3fn on everything inside the representable range (weights are scaled to
+    max 448 before the conversion), incl. every tie and every code value itself."""
+    import torch
+    F8 = torch.float8_e4m3fn
+    lib = capi.load_library()
+    allc = torch.arange(256, dtype=torch.uint8).view(F8).float().numpy()
+    allc = allc[np.isfinite(allc)]
+    pos = np.unique(np.abs(allc))
+    mids = (pos[:-1] + pos[1:]) / 2                                   # every tie
+    rng = np.random.default_rng(3)
+    x = np.concatenate([allc, mids, -mids, np.nextafter(mids, 0).astype(np.float32), np.nextafter(mids, 1e9).astype(np.float32),
+                        rng.standard_normal(20000).astype(np.float32) * 100, rng.standard_normal(20000).astype(np.float32) * 0.01,
+                        np.float32([0.0, -0.0, 448.0, -448.0, 2.0 ** -9, 2.0 ** -10, 2.0 ** -11, 1e-30, 447.9, 455.9])]).astype(np.float32)
+    x = x[np.abs(x) <= 448.0]
+    got = np.empty(x.size, np.uint8)
+    assert lib.vp_dbg_host_e4m3(x.ctypes.data, got.ctypes.data, x.size) == 0
+    ref = torch.from_numpy(x).to(F8).view(torch.uint8).numpy()
+    bad = got != ref
+    zero = (x == 0) | ((got & 0x7f) == 0) & ((ref & 0x7f) == 0)       # +-0 may differ in sign for values that round to zero
+    assert not (bad & ~zero).any(), f'{(bad & ~zero).sum()} codes differ, e.g. x={x[bad & ~zero][:5]} got={got[bad & ~zero][:5]} ref={ref[bad & ~zero][:5]}'
+    # saturation beyond the range (torch would give NaN there; the packer never produces such inputs, the converter clamps)
+    big = np.float32([460.0, 1e6, -1e6])
+    g2 = np.empty(3, np.uint8)
+    lib.vp_dbg_host_e4m3(big.ctypes.data, g2.ctypes.data, 3)
+    assert g2.tolist() == [0x7e, 0x7e, 0xfe]
