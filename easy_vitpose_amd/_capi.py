@@ -13,12 +13,12 @@ import os
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), '_lib', 'libvitpose_hip.so')
 
 VP_OK, VP_ERR_INVALID, VP_ERR_HIP, VP_ERR_STATE, VP_ERR_MISSING_TENSOR, VP_ERR_SHAPE = range(6)
-VP_DTYPE_F16, VP_DTYPE_BF16 = 0, 1
+VP_DTYPE_F16, VP_DTYPE_BF16, VP_DTYPE_FP8 = 0, 1, 2
 VP_INPUT_F32_NCHW, VP_INPUT_U8_NHWC = 0, 1
 VP_PROF_NAMES = ['gemm_proj', 'gemm_fc1', 'gemm_qkv', 'gemm_patch', 'gemm_deconv', 'gemm_final',
                  'attention', 'layernorm', 'im2col', 'decode', 'gemm_fc2']
 VP_PROF_COUNT = len(VP_PROF_NAMES)
-DTYPES = {'fp16': VP_DTYPE_F16, 'f16': VP_DTYPE_F16, 'bf16': VP_DTYPE_BF16}
+DTYPES = {'fp16': VP_DTYPE_F16, 'f16': VP_DTYPE_F16, 'bf16': VP_DTYPE_BF16, 'fp8': VP_DTYPE_FP8}
 
 # every symbol include/vitpose_hip.h declares (tests check the .so exports all of them)
 SYMBOLS = ['vp_abi_version', 'vp_create', 'vp_load_weights', 'vp_infer', 'vp_infer_device', 'vp_infer_device_stream', 'vp_host_alloc', 'vp_host_free',
@@ -27,7 +27,7 @@ SYMBOLS = ['vp_abi_version', 'vp_create', 'vp_load_weights', 'vp_infer', 'vp_inf
            'vp_infer_tokens', 'vp_decode_only', 'vp_stream', 'vp_synchronize', 'vp_set_profiling',
            'vp_reset_profile', 'vp_get_profile', 'vp_profile_kernel', 'vp_group_peer_access_missing', 'vp_destroy', 'vp_last_error',
            'vp_dbg_gemm', 'vp_dbg_attention', 'vp_dbg_layernorm', 'vp_dbg_deconv', 'vp_dbg_gemm_bench', 'vp_dbg_gemm_case', 'vp_dbg_gemm_bench2', 'vp_dbg_gemm_compare', 'vp_dbg_peak', 'vp_dbg_crop_prep',
-           'vp_dbg_group_plan', 'vp_dbg_group_trace', 'vp_dbg_fp8_gemm', 'vp_dbg_mx_gemm', 'vp_dbg_host_e4m3']
+           'vp_dbg_group_plan', 'vp_dbg_group_trace', 'vp_dbg_fp8_gemm', 'vp_dbg_mx_gemm', 'vp_dbg_host_e4m3', 'vp_dbg_gemm_fp8_case']
 
 
 class HipExtensionMissing(RuntimeError):
@@ -132,6 +132,7 @@ def load_library():
     lib.vp_dbg_fp8_gemm.argtypes = [C.c_int32] * 4 + [C.c_void_p] * 7
     lib.vp_dbg_mx_gemm.argtypes = [C.c_int32] * 4 + [C.c_void_p] * 7
     lib.vp_dbg_host_e4m3.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+    lib.vp_dbg_gemm_fp8_case.argtypes = [C.c_int32] * 5 + [C.c_void_p] * 8
     for name in SYMBOLS:
         if name not in ('vp_stream', 'vp_last_error', 'vp_host_alloc', 'vp_host_free', 'vp_group_member', 'vp_group_last_error'):
             getattr(lib, name).restype = C.c_int

@@ -111,6 +111,13 @@ __global__ __launch_bounds__(64) void mx_gemm_probe(const uint8_t* __restrict__ 
         }
 }
 
+hipError_t mx_quantize_launch(const float* src, uint8_t* codes, uint8_t* scales, int M, int K, hipStream_t s) {
+    if (M % 64 || K % 128) return hipErrorInvalidValue;
+    const size_t na = (size_t)M * (K / 32);
+    hipLaunchKernelGGL(mx_quantize_rows, dim3((unsigned)((na + 255) / 256)), dim3(256), 0, s, src, codes, scales, M, K);
+    return hipGetLastError();
+}
+
 hipError_t mx_probe_launch(const float* dA, const float* dW, const float* dWs, uint8_t* dA8, uint8_t* dAs, uint8_t* dW8, float* dOut,
                            int M, int N, int K, hipStream_t s) {
     const size_t na = (size_t)M * (K / 32), nw = (size_t)N * K / 4;

@@ -86,6 +86,12 @@ struct GemmArgs {
     int ablate;           // VP_TOOLS builds only (tools/gemm_ablate.py): 1 = no operand loads after the prologue, 2 = every tile loads the A rows of m-tile 0 (A L2-resident), 8 = no epilogue stores
     char* desc;           // host side: when non-null the launch code writes the resolved kernel's name here (desc_cap bytes)
     int desc_cap;
+    // ---- fp8 mode (gemm8f.hip; csrc/mx8.h): A = MXFP8 codes in 64 x 128 blocks (at `A`) + packed E8M0 block scales, W = e4m3 codes
+    // row-major [w_rows, K] (at `W`) + one fp32 scale per output channel; EPI_BIAS_GELU writes its output as MXFP8 (codes at `out`, K of the
+    // consumer = ldo, scales at out_scales)
+    const uint8_t* a_scales;
+    const float* w_scale;
+    uint8_t* out_scales;
 };
 hipError_t gemm_launch(int dtype, int epi, const GemmArgs& a, hipStream_t s);
 // 8-phase persistent kernel (gemm8.hip): 256 x bn tiles (bn = 256 or 192), EPI_BIAS / EPI_BIAS_GELU / EPI_BIAS_RESID_LN.
@@ -97,6 +103,17 @@ hipError_t gemm8_deferred_launch(int dtype, int epi, const GemmArgs& a, hipStrea
 #endif
 // name of the kernel a launch resolves to, as the profiler prints it minus the namespace; written by the launch code when
 // GemmArgs::desc != nullptr (vp_profile_kernel)
+
+// 8-phase kernel on MXFP8 operands (gemm8f.hip): the encoder GEMMs of the opt-in fp8 mode.  K % 256 == 0, K >= 512, M % 256 == 0.
+bool gemm8f_supported(int epi, const GemmArgs& a, int bn);
+hipError_t gemm8f_launch(int epi, const GemmArgs& a, int bn, hipStream_t s);
+// fp8 mode, between a residual GEMM and qkv / fc1 (quant8.hip): merges the producer's partial row statistics (ln_merge), normalises the
+// hi plane of the residual stream and writes it as MXFP8 (codes [Mp/64][D/128][64][128], scales packed: mx8.h); rows >= M (padding up to
+// the multiple of 256 the GEMM tiles need) are written as zeros.  LayerNorm's gamma / beta live in the consumer's weights / bias.
+hipError_t ln_quant_launch(int dtype, const uint16_t* x_hi, const float* ln_part, int tiles, uint8_t* codes, uint8_t* scales, int M, int Mp, int D,
+                           hipStream_t s);
+// fp32 rows [M, K] -> MXFP8 in the same layouts (parity taps)
+hipError_t mx_quantize_launch(const float* src, uint8_t* codes, uint8_t* scales, int M, int K, hipStream_t s);
 
 int gemm_tile_bn(int variant);   // BN of a tile configuration (number of n-tiles = ceil(N / BN))
 // fill a 16-bit buffer with pseudo-random values in [-1, 1) (benchmark operands)

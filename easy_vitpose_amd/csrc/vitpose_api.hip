@@ -3,6 +3,7 @@
 // every compute entry point needs a HIP device and fails with VP_ERR_HIP otherwise.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -57,6 +58,9 @@ struct Block {
     uint16_t *w_qkv, *w_proj, *w_fc1, *w_fc2;      // fused path: w_qkv / w_fc1 carry LayerNorm's gamma
     float *b_qkv, *b_proj, *b_fc1, *b_fc2;         // fused path: b_qkv / b_fc1 = W.beta + b
     float *s_qkv, *s_fc1;                          // fused path: row sums of the (rounded) folded weights
+    // fp8 mode: e4m3 codes [rows padded to 256][K] + one fp32 scale per output channel (LayerNorm's gamma folded into qkv / fc1 first)
+    uint8_t *w_qkv8 = nullptr, *w_fc18 = nullptr, *w_fc28 = nullptr;
+    float *ws_qkv = nullptr, *ws_fc1 = nullptr, *ws_fc2 = nullptr;
 };
 
 }  // namespace
@@ -94,6 +98,12 @@ struct vp_ctx {
     bool blocked_qkv = true;          // qkv in the same blocked layout when the head dim is 64 (a (crop, head) slab = three contiguous 8 KiB blocks; VP_BLOCKED_QKV=0: row-major)
     bool fuse_ln = true;              // LayerNorm folded into the GEMMs on both sides of it (VP_FUSE_LN=0: standalone passes)
     float *ln_part = nullptr, *rowstat = nullptr;   // partial row statistics [M][D/64][2], (mean, rstd) [M][2]
+    // fp8 mode (vp_config.dtype = VP_DTYPE_FP8; csrc/mx8.h, gemm8f.hip, quant8.hip): qkv / fc1 / fc2 on MXFP8 operands.  Token rows are
+    // padded to Mp (a multiple of the 256-row GEMM tile, >= 512); x8 / xs8 = LayerNorm(x) as MXFP8 codes / scales, hs8 = block scales of
+    // the MXFP8 `hid` (its codes live in c->hid)
+    bool fp8 = false;
+    size_t Mp = 0;
+    uint8_t *x8 = nullptr, *xs8 = nullptr, *hs8 = nullptr;
     // asynchronous host path (vp_infer_submit / vp_infer_wait): two slots, each with its own device staging, so that the
     // H2D of call i+1 and the D2H of call i-1 run on the copy stream under the compute of call i
     struct Slot {
@@ -249,6 +259,34 @@ int upload_ln_folded(vp_ctx* c, uint16_t** w_out, float** s_out, float** c_out, 
     if ((rc = upload_f32(c, s_out, s.data(), rows_pad))) return rc;
     return upload_f32(c, c_out, cc.data(), rows_pad);
 }   // weight rows: multiple of the largest BN tile (256)
+
+// fp8 mode: rows of W [N, K] (optionally with LayerNorm's gamma folded in: W'[n][k] = gamma[k] W[n][k]) -> OCP e4m3 codes with one fp32
+// scale per output channel (max |row| / 448), rows zero-padded to a multiple of 256; c_out (optional) = sum_k beta[k] W[n][k] + b[n]
+int upload_fp8_rows(vp_ctx* c, uint8_t** w_out, float** ws_out, float** c_out, const float* W, const float* b, const float* gamma,
+                    const float* beta, size_t N, size_t K) {
+    const size_t rows_pad = pad128(N);
+    std::vector<uint8_t> wq(rows_pad * K, 0);
+    std::vector<float> ws(rows_pad, 1.f), cc(rows_pad, 0.f), row(K);
+    for (size_t n = 0; n < N; ++n) {
+        float amax = 0.f;
+        double sc = 0.0;
+        for (size_t k = 0; k < K; ++k) {
+            row[k] = gamma ? gamma[k] * W[n * K + k] : W[n * K + k];
+            amax = std::fmax(amax, std::fabs(row[k]));
+            if (beta) sc += (double)beta[k] * (double)W[n * K + k];
+        }
+        const float sn = amax > 0.f ? amax / 448.0f : 1.0f;
+        ws[n] = sn;
+        for (size_t k = 0; k < K; ++k) wq[n * K + k] = vp_host_e4m3(row[k] / sn);
+        cc[n] = (float)(sc + (b ? (double)b[n] : 0.0));
+    }
+    int rc = dalloc(c, w_out, rows_pad * K);
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpy(*w_out, wq.data(), wq.size(), hipMemcpyHostToDevice));
+    if ((rc = upload_f32(c, ws_out, ws.data(), rows_pad))) return rc;
+    if (c_out) return upload_f32(c, c_out, cc.data(), rows_pad);
+    return VP_OK;
+}
 
 struct Lookup {
     std::unordered_map<std::string, const vp_tensor_desc*> map;
@@ -473,6 +511,46 @@ int gemm(vp_ctx* c, int fam, int epi, const uint16_t* A, const uint16_t* W, cons
     return VP_OK;
 }
 
+// fp8 mode: one encoder GEMM on MXFP8 operands (gemm8f.hip).  epi: EPI_BIAS (qkv -> 16-bit), EPI_BIAS_GELU (fc1 -> MXFP8 codes at `out`,
+// block scales at out_scales), EPI_BIAS_RESID_LN (fc2: two-plane residual + row statistics).  M = padded token rows (multiple of 256).
+int gemm_fp8(vp_ctx* c, int fam, int epi, const uint8_t* A8, const uint8_t* a_scales, const uint8_t* W8, const float* w_scale, const float* bias,
+             void* out, uint8_t* out_scales, const float* aux, int M, int N, int K, const LnFuse* ln) {
+    vp::GemmArgs g{};
+    g.A = (const uint16_t*)A8; g.W = (const uint16_t*)W8; g.bias = bias; g.out = out; g.aux = aux;
+    g.M = M; g.N = N; g.K = K; g.ldo = N;
+    g.a_scales = a_scales; g.w_scale = w_scale; g.out_scales = out_scales;
+    g.w_rows = (int)pad128((size_t)N);
+    if (ln) {
+        g.out_blocked = ln->out_blocked; g.reverse = ln->reverse;
+        g.plane = ln->plane; g.stats_out = ln->stats_out;
+        if (ln->tiles_out) *ln->tiles_out = N / 64;
+    }
+    // tile width: 256 for the wide GEMMs; the residual GEMM takes the width whose tile count fills the rounds of 256 persistent workgroups best
+    int bn = 256;
+    if (epi == vp::EPI_BIAS_RESID_LN) {
+        double fill = -1.0;
+        for (int cand : {256, 192}) {
+            if (N % cand) continue;
+            const long t = (long)(M / 256) * (N / cand);
+            if (t < 8) continue;
+            const double f = (double)t / (double)((t + 255) / 256 * 256);
+            if (f > fill + 1e-9) { bn = cand; fill = f; }
+        }
+    }
+    g.group_m = fam == VP_PROF_GEMM_QKV ? 4 : fam == VP_PROF_GEMM_FC2 ? 2 : 8;
+    if (!vp::gemm8f_supported(epi, g, bn))
+        return fail(c, VP_ERR_SHAPE, "fp8 mode: GEMM shape " + std::to_string(M) + " x " + std::to_string(N) + " x " + std::to_string(K) + " not supported by the MXFP8 kernel");
+    const double flops = 2.0 * M * (double)N * K;
+    double bytes = 1.0 * M * (double)K + M * (double)(K / 32) + 1.0 * N * (double)K;      // codes + block scales + weight codes
+    bytes += epi == vp::EPI_BIAS ? 2.0 * M * (double)N : epi == vp::EPI_BIAS_GELU ? (1.0 + 1.0 / 32) * M * (double)N : 8.0 * M * (double)N + 8.0 * M * (double)(N / 64);
+    char desc[192];
+    desc[0] = 0;
+    g.desc = desc; g.desc_cap = (int)sizeof(desc);
+    LAUNCH(c, fam, flops, bytes, vp::gemm8f_launch(epi, g, bn, c->stream));
+    if (desc[0] && c->kernel_desc[fam] != desc) c->kernel_desc[fam] = desc;
+    return VP_OK;
+}
+
 // forward of one chunk (n <= max_batch) with device-resident crops; heatmaps land in c->hm
 int forward_chunk(vp_ctx* c, const void* d_crops, int fmt, int n, bool want_tokens, bool flip = false) {
     const int D = c->D, M = n * 192;
@@ -481,7 +559,36 @@ int forward_chunk(vp_ctx* c, const void* d_crops, int fmt, int n, bool want_toke
     int rc;
     size_t plane = 0;   // != 0: the residual stream c->x is held as two 16-bit planes (fused-LayerNorm path)
     const bool qkv_blocked = c->blocked_qkv && D / c->heads == 64;
-    if (c->fuse_ln) {
+    if (c->fp8) {
+        // fp8 mode.  The residual stream, the attention core, attn.proj, the head and the decode are the fp16 path's; qkv / fc1 / fc2 run
+        // on MXFP8 operands.  Token rows are padded to Mp (multiple of the 256-row tile, >= 512): padding rows carry zeros into the
+        // GEMMs and are never read by a kernel that works per crop.
+        const int Mp = (int)std::max<size_t>((size_t)(M + 255) / 256 * 256, 512);
+        plane = c->Mp * (size_t)D;                   // the planes are laid out for the handle's full padded row count
+        uint16_t* xh = (uint16_t*)c->x;
+        int tiles = 0;
+        LnFuse prod; prod.plane = plane; prod.stats_out = c->ln_part; prod.tiles_out = &tiles;
+        auto quant = [&]() -> int {                  // LayerNorm(x) -> MXFP8 (replaces ln_finalize; gamma / beta live in the consumer's weights / bias)
+            LAUNCH(c, VP_PROF_LAYERNORM, 0.0, 8.0 * M * tiles + 2.0 * M * D + (1.0 + 1.0 / 32) * Mp * (double)D,
+                   vp::ln_quant_launch(c->dtype, xh, c->ln_part, tiles, c->x8, c->xs8, M, Mp, D, c->stream));
+            return VP_OK;
+        };
+        if ((rc = gemm(c, VP_PROF_GEMM_PATCH, vp::EPI_POS_LN, c->hid, c->w_patch, c->b_zero, c->x, c->pos, M, D, 768, D, 0, 0, 0, &prod))) return rc;
+        for (int l = 0; l < c->L; ++l) {
+            const Block& b = c->blocks[l];
+            if ((rc = quant())) return rc;
+            LnFuse cq; cq.out_blocked = qkv_blocked;
+            if ((rc = gemm_fp8(c, VP_PROF_GEMM_QKV, vp::EPI_BIAS, c->x8, c->xs8, b.w_qkv8, b.ws_qkv, b.b_qkv, c->qkv, nullptr, nullptr, Mp, 3 * D, D, &cq))) return rc;
+            LAUNCH(c, VP_PROF_ATTN, 4.0 * 192 * 192 * (double)D * n, 8.0 * M * D,
+                   vp::attention_launch(c->dtype, c->qkv, c->y, n, D, c->heads, c->stream, qkv_blocked ? 1 : 0));
+            LnFuse pp = prod;
+            if ((rc = gemm(c, VP_PROF_GEMM_PROJ, vp::EPI_BIAS_RESID_LN, c->y, b.w_proj, b.b_proj, c->x, c->x, M, D, D, D, 0, 0, 0, &pp))) return rc;
+            if ((rc = quant())) return rc;
+            if ((rc = gemm_fp8(c, VP_PROF_GEMM_FC1, vp::EPI_BIAS_GELU, c->x8, c->xs8, b.w_fc18, b.ws_fc1, b.b_fc1, c->hid, c->hs8, nullptr, Mp, 4 * D, D, nullptr))) return rc;
+            LnFuse p2 = prod;
+            if ((rc = gemm_fp8(c, VP_PROF_GEMM_FC2, vp::EPI_BIAS_RESID_LN, (const uint8_t*)c->hid, c->hs8, b.w_fc28, b.ws_fc2, b.b_fc2, c->x, nullptr, c->x, Mp, D, 4 * D, &p2))) return rc;
+        }
+    } else if (c->fuse_ln) {
         // LayerNorm folded into the GEMMs on both sides of it.  The residual stream is kept as two 16-bit planes
         // (x = hi + lo, same bytes as fp32, >= 22 significant bits): every producer (patch embed, attn.proj,
         // mlp.fc2) writes the planes + partial row statistics, a tiny kernel folds those into (mean, rstd), and
@@ -643,7 +750,9 @@ int vp_create(vp_handle* out, const vp_config* cfg) {
     if (hd != 32 && hd != 64 && hd != 80) return fail(nullptr, VP_ERR_INVALID, "head_dim must be 32, 64 or 80");
     if (cfg->depth <= 0 || cfg->num_keypoints <= 0 || cfg->num_keypoints > 1024 || cfg->max_batch <= 0)
         return fail(nullptr, VP_ERR_INVALID, "depth, num_keypoints and max_batch must be positive");
-    if (cfg->dtype != VP_DTYPE_F16 && cfg->dtype != VP_DTYPE_BF16) return fail(nullptr, VP_ERR_INVALID, "unknown dtype");
+    if (cfg->dtype != VP_DTYPE_F16 && cfg->dtype != VP_DTYPE_BF16 && cfg->dtype != VP_DTYPE_FP8) return fail(nullptr, VP_ERR_INVALID, "unknown dtype");
+    if (cfg->dtype == VP_DTYPE_FP8 && (D % 256 != 0 || D < 512))
+        return fail(nullptr, VP_ERR_INVALID, "the fp8 mode needs embed_dim >= 512 and a multiple of 256 (K-tiles of 128, an even number of them): ViTPose-B / -L / -H");
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
     if (e != hipSuccess || ndev <= 0)
@@ -653,13 +762,17 @@ int vp_create(vp_handle* out, const vp_config* cfg) {
     vp_ctx* c = new vp_ctx();
     c->cfg = *cfg;
     c->D = D; c->L = cfg->depth; c->heads = h; c->Kp = cfg->num_keypoints;
-    c->dtype = cfg->dtype == VP_DTYPE_F16 ? vp::DT_F16 : vp::DT_BF16;
+    c->dtype = cfg->dtype == VP_DTYPE_BF16 ? vp::DT_BF16 : vp::DT_F16;   // fp8 mode: everything that is not one of the three MXFP8 GEMMs runs as fp16
+    c->fp8 = cfg->dtype == VP_DTYPE_FP8;
     c->maxb = cfg->max_batch;
     apply_gemm_tuning(c);
     auto bail = [&](int rc) { g_create_error = c->err; vp_destroy(c); return rc; };
     if ((e = hipSetDevice(cfg->device_id)) != hipSuccess) { c->err = hipGetErrorString(e); return bail(VP_ERR_HIP); }
     if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) { c->err = hipGetErrorString(e); return bail(VP_ERR_HIP); }
-    const size_t B = (size_t)c->maxb, M = B * 192;
+    const size_t B = (size_t)c->maxb;
+    // fp8 mode: workspaces indexed by token row are sized for the padded row count the MXFP8 GEMM tiles need
+    c->Mp = std::max<size_t>((B * 192 + 255) / 256 * 256, 512);
+    const size_t M = c->fp8 ? c->Mp : B * 192;
     int rc = 0;
     void* stage = nullptr;
     if ((rc = dalloc(c, (char**)&stage, B * crop_bytes(VP_INPUT_F32_NCHW)))) return bail(rc);
@@ -690,9 +803,14 @@ int vp_create(vp_handle* out, const vp_config* cfg) {
         }
     }
 #endif
+    if (c->fp8 && !c->fuse_ln) { c->err = "the fp8 mode is built on the fused-LayerNorm path (unset VP_FUSE_LN)"; return bail(VP_ERR_INVALID); }
     if (c->fuse_ln) {
         if ((rc = dalloc(c, &c->ln_part, M * (size_t)(D / 64) * 2))) return bail(rc);
         if ((rc = dalloc(c, &c->rowstat, M * 2))) return bail(rc);
+    }
+    if (c->fp8) {
+        if ((rc = dalloc(c, &c->x8, M * D)) || (rc = dalloc(c, &c->xs8, M * (size_t)(D / 32))) || (rc = dalloc(c, &c->hs8, M * (size_t)(4 * D / 32)))) return bail(rc);
+        if (hipMemset(c->x, 0, M * D * 4) != hipSuccess) { c->err = "hipMemset"; return bail(VP_ERR_HIP); }   // padding rows of the planes: read by fc2's residual epilogue
     }
     if ((rc = dalloc(c, &c->qkv, M * 3 * D))) return bail(rc);
     if ((rc = dalloc(c, &c->hid, M * 4 * D))) return bail(rc);
@@ -739,7 +857,10 @@ int vp_load_weights(vp_handle c, const vp_tensor_desc* tensors, int32_t n_tensor
             (rc = lk.get(pre + "attn.qkv.weight", (int64_t)3 * DD, &wq)) || (rc = lk.get(pre + "attn.qkv.bias", 3 * D, &bq)) ||
             (rc = lk.get(pre + "mlp.fc1.weight", (int64_t)4 * DD, &w1)) || (rc = lk.get(pre + "mlp.fc1.bias", 4 * D, &b1)))
             return rc;
-        if (c->fuse_ln) {
+        if (c->fp8) {
+            if ((rc = upload_fp8_rows(c, &b.w_qkv8, &b.ws_qkv, &b.b_qkv, wq, bq, g1, be1, 3 * (size_t)D, D))) return rc;
+            if ((rc = upload_fp8_rows(c, &b.w_fc18, &b.ws_fc1, &b.b_fc1, w1, b1, g2, be2, 4 * (size_t)D, D))) return rc;
+        } else if (c->fuse_ln) {
             if ((rc = upload_ln_folded(c, &b.w_qkv, &b.s_qkv, &b.b_qkv, wq, bq, g1, be1, 3 * (size_t)D, D))) return rc;
             if ((rc = upload_ln_folded(c, &b.w_fc1, &b.s_fc1, &b.b_fc1, w1, b1, g2, be2, 4 * (size_t)D, D))) return rc;
         } else {
@@ -751,7 +872,9 @@ int vp_load_weights(vp_handle c, const vp_tensor_desc* tensors, int32_t n_tensor
         }
         if ((rc = lk.get(pre + "attn.proj.weight", (int64_t)DD, &p)) || (rc = upload_mat(c, &b.w_proj, p, D, D, pad128(D)))) return rc;
         if ((rc = lk.get(pre + "attn.proj.bias", D, &p)) || (rc = upload_f32(c, &b.b_proj, p, D))) return rc;
-        if ((rc = lk.get(pre + "mlp.fc2.weight", (int64_t)4 * DD, &p)) || (rc = upload_mat(c, &b.w_fc2, p, D, 4 * (size_t)D, pad128(D)))) return rc;
+        if ((rc = lk.get(pre + "mlp.fc2.weight", (int64_t)4 * DD, &p))) return rc;
+        if (c->fp8) { if ((rc = upload_fp8_rows(c, &b.w_fc28, &b.ws_fc2, nullptr, p, nullptr, nullptr, nullptr, D, 4 * (size_t)D))) return rc; }
+        else if ((rc = upload_mat(c, &b.w_fc2, p, D, 4 * (size_t)D, pad128(D)))) return rc;
         if ((rc = lk.get(pre + "mlp.fc2.bias", D, &p)) || (rc = upload_f32(c, &b.b_fc2, p, D))) return rc;
     }
     if ((rc = lk.get("backbone.last_norm.weight", D, &p)) || (rc = upload_f32(c, &c->lnf_g, p, D))) return rc;
@@ -1872,6 +1995,85 @@ VP_API int vp_dbg_mx_gemm(int32_t device, int32_t M, int32_t N, int32_t K, const
     if (e == hipSuccess && w_codes) e = hipMemcpy(w_codes, dW8, (size_t)N * K, hipMemcpyDeviceToHost);
     if (e != hipSuccess) rc = fail(c, VP_ERR_HIP, std::string("mx probe: ") + hipGetErrorString(e));
     return dbg_finish(c, rc);
+}
+
+// ONE launch of the MXFP8 GEMM kernel (gemm8f.hip) on host fp32 data (tests/test_gpu_fp8.py).  A [M,K] is quantised to MXFP8 on device
+// (mx_quantize_launch: the layouts of csrc/mx8.h), W [N,K] on the host exactly as the weight packer does (per-output-channel scale);
+// a_deq / w_deq return what the codes and scales stand for, so that the test can restate the product exactly.
+//   epi 0: out = a.w^T * w_scale + bias, rounded to fp16        epi 1: out = gelu(...) as MXFP8 (returned de-quantised)
+//   epi 6: out = ... + aux (two-plane residual, returned as hi + lo), stats [M, N/64, 2]
+VP_API int vp_dbg_gemm_fp8_case(int32_t device, int32_t epi, int32_t M, int32_t N, int32_t K, const float* A, const float* W, const float* bias,
+                                const float* aux, float* out, float* stats, float* a_deq, float* w_deq) {
+    if (M <= 0 || N <= 0 || K <= 0 || M % 256 || K % 256 || N % 64 || !A || !W || !bias || !out || (epi != 0 && epi != 1 && epi != 6))
+        return fail(nullptr, VP_ERR_INVALID, "bad fp8 gemm case");
+    vp_ctx* c = dbg_ctx(device, VP_DTYPE_F16);
+    if (!c) return VP_ERR_HIP;
+    int r;
+    const size_t MN = (size_t)M * N, MK = (size_t)M * K;
+    float *dA, *dB, *dWs, *dStats = nullptr;
+    uint8_t *dA8, *dAs, *dW8, *dOs = nullptr;
+    uint16_t* dAux16 = nullptr;
+    char* dOut;
+    if ((r = upload_f32(c, &dA, A, MK)) || (r = dalloc(c, &dA8, MK)) || (r = dalloc(c, &dAs, MK / 32)) ||
+        (r = upload_fp8_rows(c, &dW8, &dWs, nullptr, W, nullptr, nullptr, nullptr, N, K)) || (r = upload_f32(c, &dB, bias, N, pad128(N))))
+        return dbg_finish(c, r);
+    hipError_t e = vp::mx_quantize_launch(dA, dA8, dAs, M, K, nullptr);
+    if (e != hipSuccess) return dbg_finish(c, fail(c, VP_ERR_HIP, "mx quantize"));
+    const size_t out_bytes = epi == 0 ? MN * 2 : epi == 1 ? MN : MN * 4;
+    if ((r = dalloc(c, &dOut, out_bytes))) return dbg_finish(c, r);
+    hipMemset(dOut, 0xff, out_bytes);
+    LnFuse ln;
+    if (epi == 1 && (r = dalloc(c, &dOs, MN / 32))) return dbg_finish(c, r);
+    if (epi == 6) {
+        if (!aux) return dbg_finish(c, fail(c, VP_ERR_INVALID, "aux required"));
+        std::vector<uint16_t> hp(2 * MN);
+        for (size_t i = 0; i < MN; ++i) {
+            const uint16_t hi = host_to_bits(aux[i], c->dtype);
+            hp[i] = hi;
+            hp[MN + i] = host_to_bits(aux[i] - host_from_bits(hi, c->dtype), c->dtype);
+        }
+        if ((r = dalloc(c, &dAux16, 2 * MN)) || (r = dalloc(c, &dStats, (size_t)M * (N / 64) * 2))) return dbg_finish(c, r);
+        if (hipMemcpy(dAux16, hp.data(), hp.size() * 2, hipMemcpyHostToDevice) != hipSuccess) return dbg_finish(c, fail(c, VP_ERR_HIP, "H2D"));
+        ln.plane = MN; ln.stats_out = dStats;
+    }
+    r = gemm_fp8(c, epi == 0 ? VP_PROF_GEMM_QKV : epi == 1 ? VP_PROF_GEMM_FC1 : VP_PROF_GEMM_FC2, epi, dA8, dAs, dW8, dWs, dB, dOut, dOs,
+                 (const float*)dAux16, M, N, K, &ln);
+    if (!r && hipDeviceSynchronize() != hipSuccess) r = fail(c, VP_ERR_HIP, "fp8 gemm kernel failed");
+    if (r) return dbg_finish(c, r);
+    // what the operands stand for
+    {
+        std::vector<uint8_t> ca(MK), sa(MK / 32);
+        if (hipMemcpy(ca.data(), dA8, MK, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(sa.data(), dAs, MK / 32, hipMemcpyDeviceToHost) != hipSuccess)
+            return dbg_finish(c, fail(c, VP_ERR_HIP, "D2H"));
+        if (a_deq)
+            for (size_t m = 0; m < (size_t)M; ++m)
+                for (size_t k = 0; k < (size_t)K; ++k)
+                    a_deq[m * K + k] = vp_host_e4m3_to_float(ca[vp::mx_code_off(m, k, K)]) * std::ldexp(1.0f, (int)sa[vp::mx_scale_off(m, k >> 5, K)] - 127);
+        if (w_deq) {
+            std::vector<uint8_t> cw((size_t)N * K);
+            std::vector<float> sw(N);
+            if (hipMemcpy(cw.data(), dW8, cw.size(), hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(sw.data(), dWs, (size_t)N * 4, hipMemcpyDeviceToHost) != hipSuccess)
+                return dbg_finish(c, fail(c, VP_ERR_HIP, "D2H"));
+            for (size_t n = 0; n < (size_t)N; ++n)
+                for (size_t k = 0; k < (size_t)K; ++k) w_deq[n * K + k] = vp_host_e4m3_to_float(cw[n * K + k]) * sw[n];
+        }
+    }
+    if (epi == 0) {
+        r = download16(c, (const uint16_t*)dOut, out, MN);
+    } else if (epi == 1) {
+        std::vector<uint8_t> co(MN), so(MN / 32);
+        if (hipMemcpy(co.data(), dOut, MN, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(so.data(), dOs, MN / 32, hipMemcpyDeviceToHost) != hipSuccess)
+            return dbg_finish(c, fail(c, VP_ERR_HIP, "D2H"));
+        for (size_t m = 0; m < (size_t)M; ++m)
+            for (size_t n = 0; n < (size_t)N; ++n)
+                out[m * N + n] = vp_host_e4m3_to_float(co[vp::mx_code_off(m, n, N)]) * std::ldexp(1.0f, (int)so[vp::mx_scale_off(m, n >> 5, N)] - 127);
+    } else {
+        std::vector<float> hi(MN), lo(MN);
+        if ((r = download16(c, (const uint16_t*)dOut, hi.data(), MN)) || (r = download16(c, (const uint16_t*)dOut + MN, lo.data(), MN))) return dbg_finish(c, r);
+        for (size_t i = 0; i < MN; ++i) out[i] = hi[i] + lo[i];
+        if (stats && hipMemcpy(stats, dStats, (size_t)M * (N / 64) * 8, hipMemcpyDeviceToHost) != hipSuccess) return dbg_finish(c, fail(c, VP_ERR_HIP, "D2H"));
+    }
+    return dbg_finish(c, r);
 }
 
 // host-only: fp32 -> OCP e4m3 codes with the library's own converter (the one the weight packer of the fp8 mode uses)

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define VP_ABI_VERSION 3
+#define VP_ABI_VERSION 4
 #define VP_API __attribute__((visibility("default")))
 
 /* status codes (0 = ok).  The Python host maps them onto the exception types the
@@ -44,7 +44,15 @@ enum {
 
 /* arithmetic type of the GEMM/attention operands (accumulation is always fp32; LayerNorm / softmax statistics,
  * heatmaps and the decode are fp32; the residual stream is held as a hi + lo pair of 16-bit planes, >= 22 bits) */
-enum { VP_DTYPE_F16 = 0, VP_DTYPE_BF16 = 1 };
+enum {
+    VP_DTYPE_F16 = 0,
+    VP_DTYPE_BF16 = 1,
+    /* OPT-IN, never a default: the encoder's qkv / fc1 / fc2 GEMMs on MXFP8 operands (OCP e4m3 + one power-of-two scale per 32 k,
+     * csrc/mx8.h) through the block-scaled fp8 matrix instruction; residual stream, attention core, attn.proj, head and decode as in
+     * VP_DTYPE_F16.  BASELINE configs[4].  Does NOT meet the north_star's 1e-3 on confidences (e4m3 carries 3 mantissa bits; measured
+     * bounds in tests/test_gpu_fp8.py and DESIGN.md section 6); coordinates stay within +-0.5 px on peaked maps.  ViTPose-B / -L / -H only. */
+    VP_DTYPE_FP8 = 2
+};
 
 /* layout of the crop batch handed to vp_infer* */
 enum {
@@ -284,6 +292,12 @@ VP_API int vp_dbg_fp8_gemm(int32_t device_id, int32_t M, int32_t N, int32_t K, c
  * M % 64 == 0, N % 16 == 0, K % 128 == 0. */
 VP_API int vp_dbg_mx_gemm(int32_t device_id, int32_t M, int32_t N, int32_t K, const float* A, const float* W, const float* w_scale, float* out,
                           uint8_t* a_codes, uint8_t* a_scales, uint8_t* w_codes);
+/* ONE launch of the fp8 mode's GEMM kernel (csrc/gemm8f.hip) on host fp32 data: A [M,K] is quantised to MXFP8 on device, W [N,K] on the host
+ * as the weight packer does; a_deq [M,K] / w_deq [N,K] (may be NULL) return the values the codes and scales stand for.  epi 0: out = fp16(a.w^T
+ * + bias); epi 1: out = gelu(a.w^T + bias) written as MXFP8 and returned de-quantised; epi 6: out = a.w^T + bias + aux as the two-plane residual
+ * (hi + lo returned), stats [M, N/64, 2].  M % 256 == 0, K % 256 == 0, K >= 512, N % 256 == 0 (epi 6: N % 192 == 0 or N % 256 == 0). */
+VP_API int vp_dbg_gemm_fp8_case(int32_t device_id, int32_t epi, int32_t M, int32_t N, int32_t K, const float* A, const float* W, const float* bias,
+                                const float* aux, float* out, float* stats, float* a_deq, float* w_deq);
 /* HOST ONLY: fp32 -> OCP e4m3 codes with the converter the fp8 weight packer uses (round to nearest even, saturating at 448) */
 VP_API int vp_dbg_host_e4m3(const float* in, uint8_t* out, int64_t n);
 /* calibration of the box: kind 0/1 = MFMA-only loop 16x16x32 / 32x32x16 f16 (TFLOP/s), 2 = float4 copy (TB/s) */

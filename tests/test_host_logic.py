@@ -136,7 +136,7 @@ def test_library_loads_and_exports_every_header_symbol():
     for name in declared:
         assert hasattr(lib, name), f'{name} declared in the header but not exported'
     assert sorted(capi.SYMBOLS) == declared, 'ctypes binding list and header disagree'
-    assert lib.vp_abi_version() == 3
+    assert lib.vp_abi_version() == 4
     # struct layout the header promises
     assert C.sizeof(capi.vp_config) == 28 and C.sizeof(capi.vp_tensor_desc) == 24
     assert C.sizeof(capi.vp_profile) == capi.VP_PROF_COUNT * 8 * 4
