@@ -551,9 +551,9 @@ def main():
             'allgather_ms': None if ag_ms is None else round(ag_ms, 4),
         }
         if args.dtype == 'fp8':
-            line['mode_note'] = ('OPT-IN fp8 mode (BASELINE configs[4]): qkv / fc1 / fc2 on MXFP8 operands (e4m3 + one 2^k scale per 32 k) through the block-scaled fp8 MFMA; '
-                                 'attention core, attn.proj, head, decode as fp16.  Does NOT meet the north_star 1e-3 on confidences (peaked AP-10K checkpoint: max 2.8e-3, '
-                                 'coordinates max 0.20 px: tests/test_gpu_fp8.py); not a parity-grade number, reported beside the fp16 line of the same workload.')
+            line['mode_note'] = ('OPT-IN fp8 mode (BASELINE configs[4]): the encoder GEMMs on MXFP8 operands (e4m3 + one 2^k scale per 32 k) through the block-scaled fp8 MFMA, qkv / fc1 / attn.proj / fc2; '
+                                 'attention core, head, decode as fp16.  Does NOT meet the north_star 1e-3 on confidences (peaked AP-10K checkpoint: max 3.1e-3, '
+                                 'coordinates max 0.21 px: tests/test_gpu_fp8.py); not a parity-grade number, reported beside the fp16 line of the same workload.')
         if strong is not None:
             strong.pop('keypoints', None)
             line['strong_scaling_config4'] = strong

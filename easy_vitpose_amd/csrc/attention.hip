@@ -24,6 +24,7 @@
 #include <cstdlib>
 #include "common.h"
 #include "kernels.h"
+#include "mx8.h"
 
 namespace vp {
 
@@ -47,9 +48,12 @@ __device__ __forceinline__ u32x2 lds_read_tr16(const char* p) {
     return __builtin_bit_cast(u32x2, v);
 }
 
-template <class Ty, int HD, int QT>
+// MX (fp8 mode, HD = 64 only): the output is written as MXFP8 -- e4m3 codes in the 64 x 128-blocked layout + one E8M0 scale per 32 columns
+// (csrc/mx8.h) -- the A operand of the fp8 attn.proj GEMM; `out` then points at the codes and `out_scales` at the scale bytes.  A block of 32
+// output columns (half a head) of one query is the four lanes fg = 0..3 of a d-pair: amax by two cross-lane steps.
+template <class Ty, int HD, int QT, bool MX = false>
 __global__ __launch_bounds__(256, QT == 3 ? 2 : 3) void attention_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out,
-                                                            int D, int heads, float scale_log2e, int blocked) {
+                                                            int D, int heads, float scale_log2e, int blocked, uint8_t* __restrict__ out_scales = nullptr) {
     using C = AttnCfg<HD>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* Ks = smem;
@@ -220,7 +224,23 @@ __global__ __launch_bounds__(256, QT == 3 ? 2 : 3) void attention_kernel(const u
             for (int t = 0; t < QT; ++t) {
                 const int q = (wave * 3 + t0 + t) * 16 + fr;
                 uint16_t* dst = out + ((size_t)b * T + q) * D + h * HD;
-                if constexpr (C::PAIR) {   // accumulator rows of the pair = d 16 dp + 8 fg + {0..3} and + {4..7}
+                if constexpr (MX && C::PAIR) {
+                    float v[8];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { v[e] = o[0][t][e] * inv_l[t]; v[4 + e] = o[1][t][e] * inv_l[t]; }
+                    float amax = 0.f;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) amax = fmaxf(amax, fabsf(v[e]));
+                    amax = fmaxf(amax, __shfl_xor(amax, 16, 64));
+                    amax = fmaxf(amax, __shfl_xor(amax, 32, 64));
+                    const uint32_t E = mx_scale_byte(amax);
+                    const float inv = mx_inv_scale(E);
+                    const size_t m = (size_t)b * T + q;
+                    const int col = h * HD + dp * 16;                       // first column of this 32-column block
+                    *(u32x2*)((uint8_t*)out + mx_code_off(m, (size_t)col + fg * 8, (size_t)D)) =
+                        u32x2{mx_pack4(v[0], v[1], v[2], v[3], inv), mx_pack4(v[4], v[5], v[6], v[7], inv)};
+                    if (fg == 0) out_scales[mx_scale_off(m, (size_t)(col >> 5), (size_t)D)] = (uint8_t)E;
+                } else if constexpr (C::PAIR) {   // accumulator rows of the pair = d 16 dp + 8 fg + {0..3} and + {4..7}
                     u32x4 w;
                     w[0] = pack2_nosat<Ty>(o[0][t][0] * inv_l[t], o[0][t][1] * inv_l[t]);
                     w[1] = pack2_nosat<Ty>(o[0][t][2] * inv_l[t], o[0][t][3] * inv_l[t]);
@@ -249,13 +269,19 @@ static hipError_t launch(const uint16_t* qkv, uint16_t* out, int B, int D, int h
     const float scale = 1.0f / sqrtf((float)HD);   // head_dim ** -0.5, vit.py:156
     if (blocked && HD != 64) return hipErrorInvalidValue;
     hipLaunchKernelGGL(kern, dim3(B * heads), dim3(256), AttnCfg<HD>::LDS, s, qkv, out, D, heads,
-                       scale * 1.4426950408889634f, blocked);
+                       scale * 1.4426950408889634f, blocked, (uint8_t*)nullptr);
     return hipGetLastError();
 }
 
-hipError_t attention_launch(int dtype, const uint16_t* qkv, uint16_t* out, int B, int D, int heads, hipStream_t s, int qkv_blocked) {
+hipError_t attention_launch(int dtype, const uint16_t* qkv, uint16_t* out, int B, int D, int heads, hipStream_t s, int qkv_blocked, uint8_t* mx_scales) {
     const int hd = D / heads;
     if (hd * heads != D) return hipErrorInvalidValue;
+    if (mx_scales) {   // fp8 mode: MXFP8 output (head dim 64, fp16 operands)
+        if (hd != 64 || dtype != DT_F16 || D % 128) return hipErrorInvalidValue;
+        hipLaunchKernelGGL((attention_kernel<F16, 64, 1, true>), dim3(B * heads), dim3(256), AttnCfg<64>::LDS, s, qkv, out, D, heads,
+                           (1.0f / 8.0f) * 1.4426950408889634f, qkv_blocked, mx_scales);
+        return hipGetLastError();
+    }
 #define VP_ATT(HD)                                                                           \
     if (hd == HD)                                                                            \
         return dtype == DT_F16 ? launch<F16, HD>(qkv, out, B, D, heads, s, qkv_blocked) : launch<BF16, HD>(qkv, out, B, D, heads, s, qkv_blocked);

@@ -139,7 +139,9 @@ hipError_t peak_bench(int kind, double* result);
 // qkv [B*192, 3*D] 16-bit (columns = [q | k | v] x heads x head_dim, vit.py:166-167)
 // out [B*192, D]   16-bit (columns = heads x head_dim, vit.py:176)
 // qkv_blocked (head dim 64 only): qkv in the 64 x 64-blocked layout the GEMMs write with GemmArgs::out_blocked
-hipError_t attention_launch(int dtype, const uint16_t* qkv, uint16_t* out, int B, int D, int heads, hipStream_t s, int qkv_blocked = 0);
+// mx_scales != nullptr (fp8 mode, head dim 64): the output is written as MXFP8 (codes at `out`, 64 x 128-blocked; E8M0 scales at mx_scales)
+hipError_t attention_launch(int dtype, const uint16_t* qkv, uint16_t* out, int B, int D, int heads, hipStream_t s, int qkv_blocked = 0,
+                            uint8_t* mx_scales = nullptr);
 
 // ---------------------------------------------------------------- elementwise
 // fp32 [M, D] -> LayerNorm(eps 1e-6) -> 16-bit [M, D] (out16) and/or fp32 (out32), either may be null.

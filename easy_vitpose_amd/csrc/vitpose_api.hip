@@ -59,8 +59,8 @@ struct Block {
     float *b_qkv, *b_proj, *b_fc1, *b_fc2;         // fused path: b_qkv / b_fc1 = W.beta + b
     float *s_qkv, *s_fc1;                          // fused path: row sums of the (rounded) folded weights
     // fp8 mode: e4m3 codes [rows padded to 256][K] + one fp32 scale per output channel (LayerNorm's gamma folded into qkv / fc1 first)
-    uint8_t *w_qkv8 = nullptr, *w_fc18 = nullptr, *w_fc28 = nullptr;
-    float *ws_qkv = nullptr, *ws_fc1 = nullptr, *ws_fc2 = nullptr;
+    uint8_t *w_qkv8 = nullptr, *w_fc18 = nullptr, *w_fc28 = nullptr, *w_proj8 = nullptr;   // w_proj8: head dim 64 only (the attention kernel's MXFP8 output)
+    float *ws_qkv = nullptr, *ws_fc1 = nullptr, *ws_fc2 = nullptr, *ws_proj = nullptr;
 };
 
 }  // namespace
@@ -104,6 +104,7 @@ struct vp_ctx {
     bool fp8 = false;
     size_t Mp = 0;
     uint8_t *x8 = nullptr, *xs8 = nullptr, *hs8 = nullptr;
+    uint8_t *y8 = nullptr, *ys8 = nullptr;          // head dim 64: the attention output as MXFP8 (A operand of the fp8 attn.proj)
     // asynchronous host path (vp_infer_submit / vp_infer_wait): two slots, each with its own device staging, so that the
     // H2D of call i+1 and the D2H of call i-1 run on the copy stream under the compute of call i
     struct Slot {
@@ -579,10 +580,16 @@ int forward_chunk(vp_ctx* c, const void* d_crops, int fmt, int n, bool want_toke
             if ((rc = quant())) return rc;
             LnFuse cq; cq.out_blocked = qkv_blocked;
             if ((rc = gemm_fp8(c, VP_PROF_GEMM_QKV, vp::EPI_BIAS, c->x8, c->xs8, b.w_qkv8, b.ws_qkv, b.b_qkv, c->qkv, nullptr, nullptr, Mp, 3 * D, D, &cq))) return rc;
-            LAUNCH(c, VP_PROF_ATTN, 4.0 * 192 * 192 * (double)D * n, 8.0 * M * D,
-                   vp::attention_launch(c->dtype, c->qkv, c->y, n, D, c->heads, c->stream, qkv_blocked ? 1 : 0));
             LnFuse pp = prod;
-            if ((rc = gemm(c, VP_PROF_GEMM_PROJ, vp::EPI_BIAS_RESID_LN, c->y, b.w_proj, b.b_proj, c->x, c->x, M, D, D, D, 0, 0, 0, &pp))) return rc;
+            if (c->y8) {   // head dim 64: attention writes MXFP8, attn.proj runs on the fp8 kernel too
+                LAUNCH(c, VP_PROF_ATTN, 4.0 * 192 * 192 * (double)D * n, 7.0 * M * D,
+                       vp::attention_launch(c->dtype, c->qkv, (uint16_t*)c->y8, n, D, c->heads, c->stream, qkv_blocked ? 1 : 0, c->ys8));
+                if ((rc = gemm_fp8(c, VP_PROF_GEMM_PROJ, vp::EPI_BIAS_RESID_LN, c->y8, c->ys8, b.w_proj8, b.ws_proj, b.b_proj, c->x, nullptr, c->x, Mp, D, D, &pp))) return rc;
+            } else {
+                LAUNCH(c, VP_PROF_ATTN, 4.0 * 192 * 192 * (double)D * n, 8.0 * M * D,
+                       vp::attention_launch(c->dtype, c->qkv, c->y, n, D, c->heads, c->stream, qkv_blocked ? 1 : 0));
+                if ((rc = gemm(c, VP_PROF_GEMM_PROJ, vp::EPI_BIAS_RESID_LN, c->y, b.w_proj, b.b_proj, c->x, c->x, M, D, D, D, 0, 0, 0, &pp))) return rc;
+            }
             if ((rc = quant())) return rc;
             if ((rc = gemm_fp8(c, VP_PROF_GEMM_FC1, vp::EPI_BIAS_GELU, c->x8, c->xs8, b.w_fc18, b.ws_fc1, b.b_fc1, c->hid, c->hs8, nullptr, Mp, 4 * D, D, nullptr))) return rc;
             LnFuse p2 = prod;
@@ -811,6 +818,10 @@ int vp_create(vp_handle* out, const vp_config* cfg) {
     if (c->fp8) {
         if ((rc = dalloc(c, &c->x8, M * D)) || (rc = dalloc(c, &c->xs8, M * (size_t)(D / 32))) || (rc = dalloc(c, &c->hs8, M * (size_t)(4 * D / 32)))) return bail(rc);
         if (hipMemset(c->x, 0, M * D * 4) != hipSuccess) { c->err = "hipMemset"; return bail(VP_ERR_HIP); }   // padding rows of the planes: read by fc2's residual epilogue
+        if (hd == 64 && !getenv("VP_FP8_PROJ16")) {   // VP_FP8_PROJ16=1: attn.proj stays on the fp16 kernels (parity test flips it)
+            if ((rc = dalloc(c, &c->y8, M * D)) || (rc = dalloc(c, &c->ys8, M * (size_t)(D / 32)))) return bail(rc);
+            if (hipMemset(c->y8, 0, M * D) != hipSuccess || hipMemset(c->ys8, 0, M * (size_t)(D / 32)) != hipSuccess) { c->err = "hipMemset"; return bail(VP_ERR_HIP); }   // padding rows: zero codes
+        }
     }
     if ((rc = dalloc(c, &c->qkv, M * 3 * D))) return bail(rc);
     if ((rc = dalloc(c, &c->hid, M * 4 * D))) return bail(rc);
@@ -871,6 +882,7 @@ int vp_load_weights(vp_handle c, const vp_tensor_desc* tensors, int32_t n_tensor
             if ((rc = upload_mat(c, &b.w_fc1, w1, 4 * (size_t)D, D, pad128(4 * (size_t)D))) || (rc = upload_f32(c, &b.b_fc1, b1, 4 * (size_t)D))) return rc;
         }
         if ((rc = lk.get(pre + "attn.proj.weight", (int64_t)DD, &p)) || (rc = upload_mat(c, &b.w_proj, p, D, D, pad128(D)))) return rc;
+        if (c->y8 && (rc = upload_fp8_rows(c, &b.w_proj8, &b.ws_proj, nullptr, p, nullptr, nullptr, nullptr, D, D))) return rc;
         if ((rc = lk.get(pre + "attn.proj.bias", D, &p)) || (rc = upload_f32(c, &b.b_proj, p, D))) return rc;
         if ((rc = lk.get(pre + "mlp.fc2.weight", (int64_t)4 * DD, &p))) return rc;
         if (c->fp8) { if ((rc = upload_fp8_rows(c, &b.w_fc28, &b.ws_fc2, nullptr, p, nullptr, nullptr, nullptr, D, 4 * (size_t)D))) return rc; }

@@ -25,8 +25,8 @@ pytestmark = pytest.mark.gpu
 F8 = torch.float8_e4m3fn
 
 # measured bounds of the mode (round 4, MI355X), asserted with ~1.5 x headroom; the north_star's own are KP_TOL_PX / CONF_TOL
-FP8_CONF_ERR_PEAKED = 5e-3         # peaked AP-10K checkpoint, every joint: measured 2.79e-3 (rms 9.0e-4, 76 % of the joints within 1e-3); fp16 path 6.0e-4
-FP8_HM_RMS_NOISE = 3e-2            # random-weight (noise-like) heatmaps, std 0.345: measured rms 1.84e-2, max 9.0e-2 (confidence max err 5.5e-2)
+FP8_CONF_ERR_PEAKED = 5e-3         # peaked AP-10K checkpoint, every joint: measured 3.08e-3 (rms 1.0e-3, 68 % of the joints within 1e-3; with attn.proj on fp16: 2.79e-3); fp16 path 6.0e-4
+FP8_HM_RMS_NOISE = 3.5e-2          # random-weight (noise-like) heatmaps, std 0.345: measured rms 2.18e-2, max 1.1e-1 (confidence max err 7.0e-2)
 
 
 def _gelu(x):
@@ -128,10 +128,15 @@ def test_fp8_gemm_residual_epilogue(M, N, K):
     print(f'[fp8 gemm fc2 {M}x{N}x{K}] kernel vs fp64 of its operands: worst ratio {(err / tol).max():.2f}')
 
 
-def test_fp8_mode_end_to_end_peaked_ap10k():
+@pytest.mark.parametrize('proj16', ['0', '1'])
+def test_fp8_mode_end_to_end_peaked_ap10k(monkeypatch, proj16):
     """BASELINE configs[4]'s model (ViTPose-B / AP-10K) with the peaked checkpoint: coordinates of EVERY joint within the north_star's
-    +-0.5 px of the fp32 oracle; the confidence error is measured and asserted at its real bound -- it does NOT meet the north_star's 1e-3."""
+    +-0.5 px of the fp32 oracle; the confidence error is measured and asserted at its real bound -- it does NOT meet the north_star's 1e-3.
+    proj16 = 1 (VP_FP8_PROJ16): attn.proj on the fp16 kernels (the attention core writes fp16); default: the attention core writes
+    MXFP8 and attn.proj is the fourth GEMM on the fp8 kernel."""
     from cases import peaked_crops
+    if proj16 == '1':
+        monkeypatch.setenv('VP_FP8_PROJ16', '1')
     shp = model_shape('b', 'ap10k')
     sd = synthetic_state_dict(shp, 0, peaked=True)
     crops = peaked_crops(8)
@@ -139,6 +144,7 @@ def test_fp8_mode_end_to_end_peaked_ap10k():
     kp = eng.infer(crops)
     kernels = {f: eng.profile_kernel(f) for f in ('gemm_qkv', 'gemm_fc1', 'gemm_fc2', 'gemm_proj')}
     assert all('gemm8f_kernel' in kernels[f] for f in ('gemm_qkv', 'gemm_fc1', 'gemm_fc2')), kernels
+    assert ('gemm8f_kernel' in kernels['gemm_proj']) == (proj16 == '0'), kernels
     assert np.array_equal(eng.infer(crops), kp)                                           # run-to-run
     assert np.array_equal(np.concatenate([eng.infer(crops[i:i + 1]) for i in (0, 3, 7)]), kp[[0, 3, 7]])   # crop i of the batch == crop i alone
     eng.close()
@@ -150,7 +156,7 @@ def test_fp8_mode_end_to_end_peaked_ap10k():
     dpx = np.abs(kp[..., :2] - ref[..., :2]).max(-1)
     dcf = np.abs(kp[..., 2] - ref[..., 2])
     d16 = np.abs(kp16[..., 2] - ref[..., 2])
-    print(f'[fp8 mode, b/ap10k peaked] {dpx.size} joints: coordinate max err {dpx.max():.4f} px (mean {dpx.mean():.4f}); confidence max err {dcf.max():.3e} '
+    print(f'[fp8 mode, b/ap10k peaked, proj16={proj16}] {dpx.size} joints: coordinate max err {dpx.max():.4f} px (mean {dpx.mean():.4f}); confidence max err {dcf.max():.3e} '
           f'rms {np.sqrt((dcf ** 2).mean()):.3e}, {(dcf < CONF_TOL).mean():.3f} of the joints within 1e-3  [fp16 path: max {d16.max():.3e}]   kernels: {kernels}')
     assert np.isfinite(kp).all()
     assert dpx.max() < KP_TOL_PX, 'fp8 mode: coordinates must stay inside the north_star tolerance on peaked maps'
