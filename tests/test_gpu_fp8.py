@@ -164,6 +164,30 @@ def test_fp8_mode_end_to_end_peaked_ap10k(monkeypatch, proj16):
     assert d16.max() < CONF_TOL
 
 
+@pytest.mark.parametrize('variant,dataset,conf_bound', [('l', 'coco_25', 6e-3), ('h', 'wholebody', 8e-3)])
+def test_fp8_mode_large_models_vs_reference_golden(golden_dir, variant, dataset, conf_bound):
+    """The mode on the other models it accepts, against the reference's own peaked-checkpoint keypoints: ViTPose-L (D = 1024: attn.proj / fc2 on
+    256 x 256 tiles with the register-direct residual epilogue, head dim 64 -> MXFP8 attention output) and ViTPose-H (D = 1280, head dim 80:
+    attn.proj stays on fp16, K = 133).  Coordinates inside the north_star's +-0.5 px on every joint; confidences at the mode's measured bound."""
+    import os
+    from cases import peaked_crops
+    z = np.load(os.path.join(golden_dir, f'peaked_{variant}_{dataset}.npz'))
+    n = int(z['n'])
+    shp = model_shape(variant, dataset)
+    eng = VitPoseHip(shp, synthetic_state_dict(shp, 0, peaked=True), dtype='fp8', device_id=0, max_batch=n)
+    kp = eng.infer(peaked_crops(n))
+    kernels = {f: eng.profile_kernel(f) for f in ('gemm_qkv', 'gemm_fc1', 'gemm_fc2', 'gemm_proj')}
+    eng.close()
+    ref = z['keypoints']
+    dpx = np.abs(kp[..., :2] - ref[..., :2]).max(-1)
+    dcf = np.abs(kp[..., 2] - ref[..., 2])
+    print(f'[fp8 mode, {variant}/{dataset} peaked vs reference golden] {dpx.size} joints: coordinate max err {dpx.max():.4f} px; confidence max err {dcf.max():.3e} '
+          f'rms {np.sqrt((dcf ** 2).mean()):.3e}, {(dcf < CONF_TOL).mean():.3f} within 1e-3; kernels {kernels}')
+    assert np.isfinite(kp).all() and all('gemm8f_kernel' in kernels[f] for f in ('gemm_qkv', 'gemm_fc1', 'gemm_fc2'))
+    assert dpx.max() < KP_TOL_PX
+    assert dcf.max() < conf_bound
+
+
 def test_fp8_mode_config5_batch512():
     """BASELINE configs[4] as written: ViTPose-B / AP-10K, batch 512, fp8 operands.  Full-batch properties + the heatmap error of the
     mode on the bench's random-weight checkpoint against the fp32 oracle (noise-like maps: the worst case for 3-bit operands)."""
