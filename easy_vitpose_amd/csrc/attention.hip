@@ -182,7 +182,7 @@ __global__ __launch_bounds__(256, QT == 3 ? 2 : 3) void attention_kernel(const u
             for (int kt = 0; kt < 12; ++kt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float p = __builtin_amdgcn_exp2f(s[t][kt][r] * scale_log2e - mb);
+                    const float p = softmax_p(s[t][kt][r], scale_log2e, mb);
                     s[t][kt][r] = p;
                     l += p;
                 }

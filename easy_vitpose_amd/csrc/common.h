@@ -111,6 +111,13 @@ __device__ __forceinline__ void ln_merge(const float* __restrict__ p, int tiles,
     rstd = rsqrtf(__builtin_fmaf(m2, inv_d, 1e-6f));
 }
 
+// softmax numerator 2^(s scale - mb) with the multiply-add as ONE explicit fma: under -ffp-contract=fast hipcc fuses `s * scale - mb` for most
+// elements and emits v_pk_mul + v_sub for a few, and WHICH ones depends on the surrounding code -- attention.hip and qkvattn.hip then differed in
+// the last bit of ~1 % of the probabilities (round 4).  One definition, one rounding, for every kernel that must agree bit for bit.
+__device__ __forceinline__ float softmax_p(float s, float scale_log2e, float mb) {
+    return __builtin_amdgcn_exp2f(__builtin_fmaf(s, scale_log2e, -mb));
+}
+
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef __attribute__((address_space(1))) const void* gbl_ptr_t;
 

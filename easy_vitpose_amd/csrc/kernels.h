@@ -143,6 +143,23 @@ hipError_t peak_bench(int kind, double* result);
 hipError_t attention_launch(int dtype, const uint16_t* qkv, uint16_t* out, int B, int D, int heads, hipStream_t s, int qkv_blocked = 0,
                             uint8_t* mx_scales = nullptr);
 
+// attn.qkv + attention core in one kernel (qkvattn.hip; head dim 64): tile = (pair of crops, head); the qkv tensor never reaches HBM.
+// wh / bh / sh = head-major copies of the LayerNorm-folded qkv weights / bias / row sums (qkv_head_major_launch).  y bit-identical to
+// gemm (EPI_BIAS, LayerNorm-consumer fold) + attention_launch.
+struct QkvAttnArgs {
+    const uint16_t* x_hi;     // hi plane of the residual stream [2 npairs 192, D] (un-normalised 16-bit rows)
+    const uint16_t* wh;       // [heads 192, D]
+    const float* bh;          // [heads 192]
+    const float* sh;          // [heads 192]
+    const float* rowstat;     // (mean, rstd) per token row
+    uint16_t* y;              // attention output [2 npairs 192, D]
+    int npairs, heads, D;
+    float scale_log2e;        // head_dim^-0.5 * log2(e)
+};
+bool qkvattn_supported(const QkvAttnArgs& a);
+hipError_t qkvattn_launch(int dtype, const QkvAttnArgs& a, hipStream_t s, char* desc, int desc_cap);
+hipError_t qkv_head_major_launch(const uint16_t* w, const float* b, const float* s, uint16_t* wh, float* bh, float* sh, int D, int K, hipStream_t st);
+
 // ---------------------------------------------------------------- elementwise
 // fp32 [M, D] -> LayerNorm(eps 1e-6) -> 16-bit [M, D] (out16) and/or fp32 (out32), either may be null.
 // plane != 0: x is the two-plane 16-bit residual stream (hi at x, lo `plane` elements behind) instead of fp32.

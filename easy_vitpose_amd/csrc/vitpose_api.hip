@@ -58,6 +58,8 @@ struct Block {
     uint16_t *w_qkv, *w_proj, *w_fc1, *w_fc2;      // fused path: w_qkv / w_fc1 carry LayerNorm's gamma
     float *b_qkv, *b_proj, *b_fc1, *b_fc2;         // fused path: b_qkv / b_fc1 = W.beta + b
     float *s_qkv, *s_fc1;                          // fused path: row sums of the (rounded) folded weights
+    uint16_t* w_qkvh = nullptr;                    // head dim 64: head-major copies for the fused qkv + attention kernel (qkvattn.hip)
+    float *b_qkvh = nullptr, *s_qkvh = nullptr;
     // fp8 mode: e4m3 codes [rows padded to 256][K] + one fp32 scale per output channel (LayerNorm's gamma folded into qkv / fc1 first)
     uint8_t *w_qkv8 = nullptr, *w_fc18 = nullptr, *w_fc28 = nullptr, *w_proj8 = nullptr;   // w_proj8: head dim 64 only (the attention kernel's MXFP8 output)
     float *ws_qkv = nullptr, *ws_fc1 = nullptr, *ws_fc2 = nullptr, *ws_proj = nullptr;
@@ -97,6 +99,7 @@ struct vp_ctx {
     bool blocked_hid = true;          // mlp hidden activations in the 64x64-blocked layout (VP_BLOCKED_HID=0: row-major)
     bool blocked_qkv = true;          // qkv in the same blocked layout when the head dim is 64 (a (crop, head) slab = three contiguous 8 KiB blocks; VP_BLOCKED_QKV=0: row-major)
     bool fuse_ln = true;              // LayerNorm folded into the GEMMs on both sides of it (VP_FUSE_LN=0: standalone passes)
+    bool fuse_qkv_attn = true;        // head dim 64, even batches of >= 2 tiles per CU: attn.qkv + attention core in one kernel (VP_FUSE_QKV_ATTN=0: two launches)
     float *ln_part = nullptr, *rowstat = nullptr;   // partial row statistics [M][D/64][2], (mean, rstd) [M][2]
     // fp8 mode (vp_config.dtype = VP_DTYPE_FP8; csrc/mx8.h, gemm8f.hip, quant8.hip): qkv / fc1 / fc2 on MXFP8 operands.  Token rows are
     // padded to Mp (a multiple of the 256-row GEMM tile, >= 512); x8 / xs8 = LayerNorm(x) as MXFP8 codes / scales, hs8 = block scales of
@@ -618,9 +621,23 @@ int forward_chunk(vp_ctx* c, const void* d_crops, int fmt, int n, bool want_toke
             const Block& b = c->blocks[l];
             LnFuse cq; cq.rowstat = c->rowstat; cq.ln_s = b.s_qkv; cq.reverse = (c->order_mask & 1) != 0; cq.out_blocked = qkv_blocked;
             if (fold_stats) { cq.rowstat = nullptr; cq.ln_part = c->ln_part; cq.ln_tiles = D / 64; }
+            // attn.qkv + attention core as ONE kernel per (pair of crops, head) once every CU gets >= 2 tiles (qkvattn.hip; bit-identical y)
+            if (b.w_qkvh && !fold_stats && (n & 1) == 0 && (long)(n / 2) * c->heads >= 512 && c->gemm_variant[VP_PROF_GEMM_QKV] < 0) {
+                vp::QkvAttnArgs qa{};
+                qa.x_hi = xh; qa.wh = b.w_qkvh; qa.bh = b.b_qkvh; qa.sh = b.s_qkvh; qa.rowstat = c->rowstat; qa.y = c->y;
+                qa.npairs = n / 2; qa.heads = c->heads; qa.D = D;
+                const float scale = 1.0f / sqrtf(64.0f);
+                qa.scale_log2e = scale * 1.4426950408889634f;
+                char desc[96];
+                desc[0] = 0;
+                LAUNCH(c, VP_PROF_GEMM_QKV, 2.0 * M * 3.0 * D * D + 4.0 * 192 * 192 * (double)D * n, 2.0 * M * D + 2.0 * 3 * D * (double)D + 2.0 * M * D,
+                       vp::qkvattn_launch(c->dtype, qa, c->stream, desc, (int)sizeof(desc)));
+                if (desc[0] && c->kernel_desc[VP_PROF_GEMM_QKV] != desc) c->kernel_desc[VP_PROF_GEMM_QKV] = desc;
+            } else {
             if ((rc = gemm(c, VP_PROF_GEMM_QKV, vp::EPI_BIAS, xh, b.w_qkv, b.b_qkv, c->qkv, nullptr, M, 3 * D, D, 3 * D, 0, 0, 0, &cq))) return rc;
             LAUNCH(c, VP_PROF_ATTN, 4.0 * 192 * 192 * (double)D * n, 8.0 * M * D,
                    vp::attention_launch(c->dtype, c->qkv, c->y, n, D, c->heads, c->stream, qkv_blocked ? 1 : 0));
+            }
             LnFuse pp = prod; pp.reverse = (c->order_mask & 2) != 0;
             if ((rc = gemm(c, VP_PROF_GEMM_PROJ, vp::EPI_BIAS_RESID_LN, c->y, b.w_proj, b.b_proj, c->x, c->x, M, D, D, D, 0, 0, 0, &pp))) return rc;
             if ((rc = finalize())) return rc;
@@ -795,6 +812,7 @@ int vp_create(vp_handle* out, const vp_config* cfg) {
     if (const char* f = getenv("VP_FUSE_HEAD")) c->fuse_head = atoi(f) != 0;
     if (const char* f = getenv("VP_FOLD_STATS")) c->graph_max_n_stats = atoi(f);
     if (const char* f = getenv("VP_BLOCKED_QKV")) c->blocked_qkv = atoi(f) != 0;
+    if (const char* f = getenv("VP_FUSE_QKV_ATTN")) c->fuse_qkv_attn = atoi(f) != 0;
     if (const char* f = getenv("VP_GEMM8")) c->gemm8_mask = atoi(f);   // which GEMMs may take the 8-phase kernel (1 fc2, 2 fc1, 4 qkv, 8 proj; 0 = the 2-phase kernels everywhere)
 #ifdef VP_TOOLS   // development switches of the measurement build (tools/)
     if (const char* f = getenv("VP_BLOCKED_HID")) c->blocked_hid = atoi(f) != 0;
@@ -873,6 +891,10 @@ int vp_load_weights(vp_handle c, const vp_tensor_desc* tensors, int32_t n_tensor
             if ((rc = upload_fp8_rows(c, &b.w_fc18, &b.ws_fc1, &b.b_fc1, w1, b1, g2, be2, 4 * (size_t)D, D))) return rc;
         } else if (c->fuse_ln) {
             if ((rc = upload_ln_folded(c, &b.w_qkv, &b.s_qkv, &b.b_qkv, wq, bq, g1, be1, 3 * (size_t)D, D))) return rc;
+            if (c->fuse_qkv_attn && D / c->heads == 64) {   // head-major copies for the fused qkv + attention kernel
+                if ((rc = dalloc(c, &b.w_qkvh, 3 * (size_t)D * D)) || (rc = dalloc(c, &b.b_qkvh, 3 * (size_t)D)) || (rc = dalloc(c, &b.s_qkvh, 3 * (size_t)D))) return rc;
+                HIPCHK(c, vp::qkv_head_major_launch(b.w_qkv, b.b_qkv, b.s_qkv, b.w_qkvh, b.b_qkvh, b.s_qkvh, D, D, nullptr));
+            }
             if ((rc = upload_ln_folded(c, &b.w_fc1, &b.s_fc1, &b.b_fc1, w1, b1, g2, be2, 4 * (size_t)D, D))) return rc;
         } else {
             if ((rc = upload_f32(c, &b.ln1_g, g1, D)) || (rc = upload_f32(c, &b.ln1_b, be1, D)) ||
@@ -1539,6 +1561,35 @@ VP_API int vp_dbg_attention(int32_t device, int32_t dtype, int32_t B, int32_t D,
     if (e == hipSuccess) e = hipDeviceSynchronize();
     if (e != hipSuccess) return dbg_finish(c, fail(c, VP_ERR_HIP, std::string("attention: ") + hipGetErrorString(e)));
     return dbg_finish(c, download16(c, dout, out, M * D));
+}
+
+// attn.qkv + attention core in one kernel (qkvattn.hip): x [2 npairs 192, D] (rounded to dtype), Wqkv [3D, D], bias [3D] -> out [M, D] (as fp32).
+// Run with neutral LayerNorm statistics (mean 0, rstd 1, row sums 0: ln_fold(acc, 0, 0, 1, b) == acc + b exactly), so the result must equal
+// vp_dbg_gemm(epi 0) followed by vp_dbg_attention bit for bit.
+VP_API int vp_dbg_qkvattn(int32_t device, int32_t dtype, int32_t npairs, int32_t D, int32_t heads, const float* x, const float* W, const float* bias, float* out) {
+    if (npairs <= 0 || D <= 0 || heads <= 0 || !x || !W || !bias || !out) return fail(nullptr, VP_ERR_INVALID, "bad qkvattn test shape");
+    vp_ctx* c = dbg_ctx(device, dtype);
+    if (!c) return VP_ERR_HIP;
+    const size_t M = (size_t)npairs * 384;
+    uint16_t *dx, *dw, *dwh, *dy;
+    float *db, *dbh, *ds, *dsh, *drow;
+    int rc;
+    std::vector<float> zeros(3 * (size_t)D, 0.f), row(2 * M);
+    for (size_t m = 0; m < M; ++m) { row[2 * m] = 0.f; row[2 * m + 1] = 1.f; }
+    if ((rc = upload_mat(c, &dx, x, M, D, M)) || (rc = upload_mat(c, &dw, W, 3 * (size_t)D, D, pad128(3 * (size_t)D))) || (rc = upload_f32(c, &db, bias, 3 * (size_t)D)) ||
+        (rc = upload_f32(c, &ds, zeros.data(), 3 * (size_t)D)) || (rc = upload_f32(c, &drow, row.data(), 2 * M)) || (rc = dalloc(c, &dwh, 3 * (size_t)D * D)) ||
+        (rc = dalloc(c, &dbh, 3 * (size_t)D)) || (rc = dalloc(c, &dsh, 3 * (size_t)D)) || (rc = dalloc(c, &dy, M * D)))
+        return dbg_finish(c, rc);
+    hipError_t e = vp::qkv_head_major_launch(dw, db, ds, dwh, dbh, dsh, D, D, nullptr);
+    vp::QkvAttnArgs qa{};
+    qa.x_hi = dx; qa.wh = dwh; qa.bh = dbh; qa.sh = dsh; qa.rowstat = drow; qa.y = dy; qa.npairs = npairs; qa.heads = heads; qa.D = D;
+    const float scale = 1.0f / sqrtf(64.0f);
+    qa.scale_log2e = scale * 1.4426950408889634f;
+    if (e == hipSuccess && !vp::qkvattn_supported(qa)) return dbg_finish(c, fail(c, VP_ERR_INVALID, "shape not supported by the fused qkv + attention kernel"));
+    if (e == hipSuccess) e = vp::qkvattn_launch(c->dtype, qa, nullptr, nullptr, 0);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e != hipSuccess) return dbg_finish(c, fail(c, VP_ERR_HIP, std::string("qkvattn: ") + hipGetErrorString(e)));
+    return dbg_finish(c, download16(c, dy, out, M * D));
 }
 
 // LayerNorm(eps 1e-6): x [M,D] fp32 -> out16 (as fp32) [M,D] and out32 [M,D]

@@ -240,6 +240,10 @@ VP_API int vp_dbg_gemm(int32_t device_id, int32_t dtype, int32_t epi, int32_t M,
 /* qkv [B*192, 3*D] -> attention core output [B*192, D]  (vit.py:167-176) */
 VP_API int vp_dbg_attention(int32_t device_id, int32_t dtype, int32_t B, int32_t D, int32_t heads,
                             const float* qkv, float* out);
+/* attn.qkv + attention core in ONE kernel (csrc/qkvattn.hip; head dim 64): x [2 npairs 192, D], Wqkv [3D, D], bias [3D] -> [M, D].  Neutral
+ * LayerNorm statistics: the result must equal vp_dbg_gemm(epi 0) + vp_dbg_attention bit for bit.  npairs * heads >= 8. */
+VP_API int vp_dbg_qkvattn(int32_t device_id, int32_t dtype, int32_t npairs, int32_t D, int32_t heads, const float* x, const float* W,
+                          const float* bias, float* out);
 /* LayerNorm(eps=1e-6) of x [M,D]: out16 = result rounded to dtype (returned as fp32), out32 = fp32 result */
 VP_API int vp_dbg_layernorm(int32_t device_id, int32_t dtype, int32_t M, int32_t D, const float* x,
                             const float* gamma, const float* beta, float* out16, float* out32);

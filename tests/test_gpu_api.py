@@ -187,6 +187,34 @@ def test_mid_batch_gemm8_selection_is_bit_identical(monkeypatch, n):
     assert np.array_equal(kp, ref_kp)
 
 
+@pytest.mark.parametrize('variant,dataset,dtype,n', [('b', 'coco', 'fp16', 96), ('l', 'coco_25', 'fp16', 64), ('b', 'coco', 'bf16', 128), ('b', 'coco', 'fp16', 256)])
+def test_fused_qkv_attention_is_bit_identical(monkeypatch, variant, dataset, dtype, n):
+    """attn.qkv + the attention core in one kernel per (pair of crops, head) (qkvattn.hip: 384 x 192 tiles on the 8-phase schedule, q / k / v handed
+    to the attention core through LDS, the [M, 3D] tensor never in HBM) against the two-launch path (VP_FUSE_QKV_ATTN=0): same accumulation order,
+    same LayerNorm fold, same roundings, same attention arithmetic -> backbone tokens and keypoints must not differ by a bit; repeated, because a
+    ring / barrier race would show up as run-to-run differences."""
+    shp, sd, _ = weights(variant, dataset)
+    crops = synthetic_crops(n, 51, 'blobs')
+    crops[n // 2:] = synthetic_crops(n - n // 2, 52, 'noise')
+    monkeypatch.setenv('VP_FUSE_QKV_ATTN', '0')
+    eng = VitPoseHip(shp, sd, dtype=dtype, max_batch=n)
+    ref_kp, ref_tok = eng.infer(crops), eng.tokens(crops)
+    ref_kernel = eng.profile_kernel('gemm_qkv')
+    eng.close()
+    monkeypatch.delenv('VP_FUSE_QKV_ATTN')
+    eng = VitPoseHip(shp, sd, dtype=dtype, max_batch=n)
+    runs = [(eng.infer(crops), eng.tokens(crops)) for _ in range(3)]
+    kernel = eng.profile_kernel('gemm_qkv')
+    odd = eng.infer(crops[:n - 1])                      # an odd batch takes the two-launch path
+    eng.close()
+    print(f'[{variant}/{dtype} @ {n}] qkv family: {ref_kernel!r} vs {kernel!r}')
+    assert 'qkvattn_kernel' in kernel and 'qkvattn_kernel' not in ref_kernel
+    for kp, tok in runs:
+        assert np.array_equal(tok, ref_tok), f'{(tok != ref_tok).any(axis=(1, 2)).sum()} of {n} crops differ in the backbone output'
+        assert np.array_equal(kp, ref_kp)
+    assert np.array_equal(odd, ref_kp[:n - 1])
+
+
 def test_group_matches_single_handle():
     """vp_group_* with every visible device (1 on the test box): sharded result == unsharded result, bit for bit; the
     device-side all-gather leaves all keypoints on every member."""
