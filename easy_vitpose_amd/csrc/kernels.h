@@ -155,6 +155,7 @@ struct QkvAttnArgs {
     uint16_t* y;              // attention output [2 npairs 192, D]
     int npairs, heads, D;
     float scale_log2e;        // head_dim^-0.5 * log2(e)
+    int ablate;               // VP_TOOLS builds only (tools/qkvattn_phases.py): 1 = no attention phase, 2 = no epilogue (LDS hand-over), 4 = no K-loop, 8 = no ring restart wait
 };
 bool qkvattn_supported(const QkvAttnArgs& a);
 hipError_t qkvattn_launch(int dtype, const QkvAttnArgs& a, hipStream_t s, char* desc, int desc_cap);

@@ -42,7 +42,7 @@ __device__ __forceinline__ u32x2 lds_read_tr16(const char* p) {
 }
 }  // namespace
 
-template <class T>
+template <class T, int QT>
 __global__ __launch_bounds__(512, 2) void qkvattn_kernel(QkvAttnArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -187,39 +187,44 @@ __global__ __launch_bounds__(512, 2) void qkvattn_kernel(QkvAttnArgs g) {
         ktile(B0{}, M1{}, 1, 2);
         ktile(B1{}, M0{}, 2, 3);
         for (int kt = 2; kt < nk - 2; kt += 2) {
+            if (VP_ABLATE(g) & 4) break;
             ktile(B0{}, M0{}, kt + 1, kt + 2);
             ktile(B1{}, M0{}, kt + 2, kt + 3);
         }
         // the last two K-tiles keep the issue pattern (and with it the wait counts) by fetching K-tiles 0 / 1 of this tile once more: valid, unused
         ktile(B0{}, M0{}, nk - 1, 0);
         ktile(B1{}, M0{}, 0, 1);
+        // operands of the epilogue (bias, row sums, this lane's 12 row statistics) are requested HERE, in front of the drain of the ring: their
+        // L2 latency then hides behind the wait for the run-ahead DMAs and the two barriers instead of in front of the first LDS store
+        int frow_e = frow, fg_e = fg;
+        asm volatile("" : "+v"(frow_e), "+v"(fg_e));
+        // this lane's weight rows (tile columns): fragment f = 0 / 1: head * 192 + wc 32 + f 16 + fg 4 + e; f = 2: head * 192 + 128 + wc 16 + fg 4 + e
+        const int cb = head * 192 + fg_e * 4;
+        f32x4 b4[3], s4[3];
+        float2 stat[12];
+#pragma unroll
+        for (int f = 0; f < 3; ++f) {
+            const int c = cb + (f < 2 ? wc * 32 + f * 16 : 128 + wc * 16);
+            b4[f] = *(const f32x4*)(g.bh + c);
+            s4[f] = *(const f32x4*)(g.sh + c);
+        }
+        const float* rs0 = g.rowstat + 2 * ((size_t)pair * 384 + wr * 96 + frow_e);   // crop 0 of the pair; crop 1: + 2 * 192 floats
+#pragma unroll
+        for (int j = 0; j < 6; ++j) stat[j] = *(const float2*)(rs0 + 32 * j);          // crop 1's six follow inside the epilogue, under crop 0's stores
         wait_vm<0>();
         if (!wr) bar();     // undo the stagger: both groups meet here
         __syncthreads();    // every wave is done with the ring
 
         // ---------------- qkv epilogue: LayerNorm fold + bias -> 16 bit -> LDS (attention layouts) ----------------
-        {
-            int frow_e = frow, fg_e = fg;
-            asm volatile("" : "+v"(frow_e), "+v"(fg_e));
-            // this lane's weight rows (tile columns): fragment f = 0 / 1: head * 192 + wc 32 + f 16 + fg 4 + e; f = 2: head * 192 + 128 + wc 16 + fg 4 + e
-            const int cb = head * 192 + fg_e * 4;
-            f32x4 b4[3], s4[3];
-#pragma unroll
-            for (int f = 0; f < 3; ++f) {
-                const int c = cb + (f < 2 ? wc * 32 + f * 16 : 128 + wc * 16);
-                b4[f] = *(const f32x4*)(g.bh + c);
-                s4[f] = *(const f32x4*)(g.sh + c);
-            }
+        if (!(VP_ABLATE(g) & 2)) {
             const int dcol = wc * 16 + fg_e * 4;                                   // head-dim column of this lane's four values
             const int qk_byte = (fg_e & 1) * 8;                                    // inside the 16-byte slot d >> 3 = wc 2 + (fg >> 1)
             const int qk_slot = wc * 2 + (fg_e >> 1);
             const int v_sub = 2 * (wc >> 1) + (fg_e & 1);                          // attention.hip: d 8 ch .. + 3 -> sub-tile 2 (ch / 4), + 4 .. + 7 -> 2 (ch / 4) + 1
             const int v_byte = ((wc & 1) * 2 + (fg_e >> 1)) * 8;
             (void)dcol;
-            float2 stat[12];                                                        // (mean, rstd) of this lane's 12 rows: all loads in flight at once
 #pragma unroll
-            for (int j = 0; j < 12; ++j)
-                stat[j] = *(const float2*)(g.rowstat + 2 * (((size_t)pair * 2 + j / 6) * 192 + wr * 96 + (j % 6) * 16 + frow_e));
+            for (int j = 6; j < 12; ++j) stat[j] = *(const float2*)(rs0 + 384 + 32 * (j - 6));
 #pragma unroll
             for (int j = 0; j < 12; ++j) {
                 const int crop = j / 6;
@@ -241,7 +246,7 @@ __global__ __launch_bounds__(512, 2) void qkvattn_kernel(QkvAttnArgs g) {
         __syncthreads();
 
         // ---------------- attention core (attention.hip, one query tile live at a time): waves 0-3 crop 0, waves 4-7 crop 1 ----------------
-        {
+        if (!(VP_ABLATE(g) & 1)) {
             const int crop = wave >> 2, lw = wave & 3;
             const char* Qs = smem + crop * QA::CROP;
             const char* Ks = Qs + QA::XS;
@@ -254,54 +259,67 @@ __global__ __launch_bounds__(512, 2) void qkvattn_kernel(QkvAttnArgs g) {
             const int kswz = (fr >> 1) & 7;
             const char* vfrag = Vs + (fg * 4 + (fr >> 2)) * 32 + (fr & 3) * 8;
             const size_t b = (size_t)pair * 2 + crop;
+            // QT query tiles of the wave at a time.  QT = 3 (the accumulators are dead: 256 registers for this phase): every K / V^T fragment read from
+            // LDS feeds three MFMAs; QT = 1: attention.hip's shipped form.  Per query tile the arithmetic is attention.hip's, instruction for instruction.
 #pragma unroll
-            for (int tq_ = 0; tq_ < 3; ++tq_) {
-                const int q = (lw * 3 + tq_) * 16 + fr;
-                u32x4 qf[2];
+            for (int t0 = 0; t0 < 3; t0 += QT) {
+                u32x4 qf[QT][2];
 #pragma unroll
-                for (int kk = 0; kk < 2; ++kk) qf[kk] = *(const u32x4*)(Qs + q * 128 + (((kk * 4 + fg) ^ kswz) << 4));
-                f32x4 s[12];
+                for (int tq_ = 0; tq_ < QT; ++tq_)
 #pragma unroll
-                for (int kt = 0; kt < 12; ++kt) s[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    for (int kk = 0; kk < 2; ++kk) qf[tq_][kk] = *(const u32x4*)(Qs + ((lw * 3 + t0 + tq_) * 16 + fr) * 128 + (((kk * 4 + fg) ^ kswz) << 4));
+                f32x4 s[QT][12];
+#pragma unroll
+                for (int tq_ = 0; tq_ < QT; ++tq_)
+#pragma unroll
+                    for (int kt = 0; kt < 12; ++kt) s[tq_][kt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int kt = 0; kt < 12; ++kt)
 #pragma unroll
                     for (int kk = 0; kk < 2; ++kk) {
                         const u32x4 kf = *(const u32x4*)(kfrag + kt * 16 * 128 + (((kk * 4 + fg) ^ kswz) << 4));
-                        s[kt] = mfma16<T>(kf, qf[kk], s[kt]);
+#pragma unroll
+                        for (int tq_ = 0; tq_ < QT; ++tq_) s[tq_][kt] = mfma16<T>(kf, qf[tq_][kk], s[tq_][kt]);
                     }
-                float mx = -3.0e38f;
+                u32x4 pf[QT][6];
+                float inv_l[QT];
 #pragma unroll
-                for (int kt = 0; kt < 12; ++kt)
+                for (int tq_ = 0; tq_ < QT; ++tq_) {
+                    float mx = -3.0e38f;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[kt][r]);
-                mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-                float l = 0.f;
-                const float mb = mx * g.scale_log2e;
+                    for (int kt = 0; kt < 12; ++kt)
 #pragma unroll
-                for (int kt = 0; kt < 12; ++kt)
+                        for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[tq_][kt][r]);
+                    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+                    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                    float l = 0.f;
+                    const float mb = mx * g.scale_log2e;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float p = softmax_p(s[kt][r], g.scale_log2e, mb);
-                        s[kt][r] = p;
-                        l += p;
+                    for (int kt = 0; kt < 12; ++kt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float p = softmax_p(s[tq_][kt][r], g.scale_log2e, mb);
+                            s[tq_][kt][r] = p;
+                            l += p;
+                        }
+                    l += __shfl_xor(l, 16, 64);
+                    l += __shfl_xor(l, 32, 64);
+                    inv_l[tq_] = 1.0f / l;
+#pragma unroll
+                    for (int kb = 0; kb < 6; ++kb) {
+                        pf[tq_][kb][0] = pack2_nosat<T>(s[tq_][2 * kb][0], s[tq_][2 * kb][1]);
+                        pf[tq_][kb][1] = pack2_nosat<T>(s[tq_][2 * kb][2], s[tq_][2 * kb][3]);
+                        pf[tq_][kb][2] = pack2_nosat<T>(s[tq_][2 * kb + 1][0], s[tq_][2 * kb + 1][1]);
+                        pf[tq_][kb][3] = pack2_nosat<T>(s[tq_][2 * kb + 1][2], s[tq_][2 * kb + 1][3]);
                     }
-                l += __shfl_xor(l, 16, 64);
-                l += __shfl_xor(l, 32, 64);
-                const float inv_l = 1.0f / l;
-                u32x4 pf[6];
-#pragma unroll
-                for (int kb = 0; kb < 6; ++kb) {
-                    pf[kb][0] = pack2_nosat<T>(s[2 * kb][0], s[2 * kb][1]);
-                    pf[kb][1] = pack2_nosat<T>(s[2 * kb][2], s[2 * kb][3]);
-                    pf[kb][2] = pack2_nosat<T>(s[2 * kb + 1][0], s[2 * kb + 1][1]);
-                    pf[kb][3] = pack2_nosat<T>(s[2 * kb + 1][2], s[2 * kb + 1][3]);
                 }
-                uint16_t* dst = g.y + (b * 192 + q) * g.D + head * 64;
 #pragma unroll
                 for (int dp = 0; dp < 4; dp += 2) {
-                    f32x4 o[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+                    f32x4 o[2][QT];
+#pragma unroll
+                    for (int u = 0; u < 2; ++u)
+#pragma unroll
+                        for (int tq_ = 0; tq_ < QT; ++tq_) o[u][tq_] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                     for (int kb = 0; kb < 6; ++kb)
 #pragma unroll
@@ -309,14 +327,21 @@ __global__ __launch_bounds__(512, 2) void qkvattn_kernel(QkvAttnArgs g) {
                             const char* vp_ = vfrag + (dp + u) * QA::VSUB + kb * 1024;
                             const u32x2 lo = lds_read_tr16(vp_);
                             const u32x2 hi = lds_read_tr16(vp_ + 512);
-                            o[u] = mfma16<T>(u32x4{lo[0], lo[1], hi[0], hi[1]}, pf[kb], o[u]);
+                            const u32x4 vf = u32x4{lo[0], lo[1], hi[0], hi[1]};
+#pragma unroll
+                            for (int tq_ = 0; tq_ < QT; ++tq_) o[u][tq_] = mfma16<T>(vf, pf[tq_][kb], o[u][tq_]);
                         }
-                    u32x4 w;
-                    w[0] = pack2_nosat<T>(o[0][0] * inv_l, o[0][1] * inv_l);
-                    w[1] = pack2_nosat<T>(o[0][2] * inv_l, o[0][3] * inv_l);
-                    w[2] = pack2_nosat<T>(o[1][0] * inv_l, o[1][1] * inv_l);
-                    w[3] = pack2_nosat<T>(o[1][2] * inv_l, o[1][3] * inv_l);
-                    *(u32x4*)(dst + dp * 16 + fg * 8) = w;
+#pragma unroll
+                    for (int tq_ = 0; tq_ < QT; ++tq_) {
+                        const int q = (lw * 3 + t0 + tq_) * 16 + fr;
+                        uint16_t* dst = g.y + (b * 192 + q) * g.D + head * 64;
+                        u32x4 w;
+                        w[0] = pack2_nosat<T>(o[0][tq_][0] * inv_l[tq_], o[0][tq_][1] * inv_l[tq_]);
+                        w[1] = pack2_nosat<T>(o[0][tq_][2] * inv_l[tq_], o[0][tq_][3] * inv_l[tq_]);
+                        w[2] = pack2_nosat<T>(o[1][tq_][0] * inv_l[tq_], o[1][tq_][1] * inv_l[tq_]);
+                        w[3] = pack2_nosat<T>(o[1][tq_][2] * inv_l[tq_], o[1][tq_][3] * inv_l[tq_]);
+                        *(u32x4*)(dst + dp * 16 + fg * 8) = w;
+                    }
                 }
             }
         }
@@ -367,7 +392,8 @@ hipError_t qkvattn_launch(int dtype, const QkvAttnArgs& a, hipStream_t s, char* 
     int dev = 0;
     (void)hipGetDevice(&dev);
     const int di = dtype == DT_F16 ? 0 : 1;
-    auto kern = dtype == DT_F16 ? qkvattn_kernel<F16> : qkvattn_kernel<BF16>;
+    static const int qt = [] { const char* e = getenv("VP_QA_QT"); return e && atoi(e) == 1 ? 1 : 3; }();   // A/B of the attention phase's two forms (both bit-identical)
+    auto kern = dtype == DT_F16 ? (qt == 1 ? qkvattn_kernel<F16, 1> : qkvattn_kernel<F16, 3>) : (qt == 1 ? qkvattn_kernel<BF16, 1> : qkvattn_kernel<BF16, 3>);
     if (dev < 0 || dev >= 64 || !attr_done[di][dev]) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, QA::RING);
         if (e != hipSuccess) return e;

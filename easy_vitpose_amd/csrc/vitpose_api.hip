@@ -1592,6 +1592,42 @@ VP_API int vp_dbg_qkvattn(int32_t device, int32_t dtype, int32_t npairs, int32_t
     return dbg_finish(c, download16(c, dy, out, M * D));
 }
 
+#ifdef VP_TOOLS
+// tools/qkvattn_phases.py: average milliseconds of the fused qkv + attention kernel on random operands, optionally with phases compiled out
+VP_API int vp_dbg_qkvattn_bench(int32_t device, int32_t npairs, int32_t D, int32_t heads, int32_t iters, int32_t ablate, float* ms_out) {
+    vp_ctx* c = dbg_ctx(device, VP_DTYPE_F16);
+    if (!c) return VP_ERR_HIP;
+    const size_t M = (size_t)npairs * 384;
+    uint16_t *dx, *dwh, *dy;
+    float *dbh, *dsh, *drow;
+    int rc;
+    if ((rc = dalloc(c, &dx, M * D)) || (rc = dalloc(c, &dwh, 3 * (size_t)D * D)) || (rc = dalloc(c, &dy, M * D)) || (rc = dalloc(c, &dbh, 3 * (size_t)D)) ||
+        (rc = dalloc(c, &dsh, 3 * (size_t)D)) || (rc = dalloc(c, &drow, 2 * M)))
+        return dbg_finish(c, rc);
+    vp::fill_random16(c->dtype, dx, M * D, 1u, nullptr);
+    vp::fill_random16(c->dtype, dwh, 3 * (size_t)D * D, 2u, nullptr);
+    hipMemset(dbh, 0, 3 * (size_t)D * 4); hipMemset(dsh, 0, 3 * (size_t)D * 4); hipMemset(drow, 0, 2 * M * 4);
+    vp::QkvAttnArgs qa{};
+    qa.x_hi = dx; qa.wh = dwh; qa.bh = dbh; qa.sh = dsh; qa.rowstat = drow; qa.y = dy; qa.npairs = npairs; qa.heads = heads; qa.D = D; qa.ablate = ablate;
+    qa.scale_log2e = 0.125f * 1.4426950408889634f;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    hipError_t e = hipSuccess;
+    for (int i = 0; i < 2 && e == hipSuccess; ++i) e = vp::qkvattn_launch(c->dtype, qa, nullptr, nullptr, 0);
+    hipDeviceSynchronize();
+    hipEventRecord(e0, nullptr);
+    for (int i = 0; i < iters && e == hipSuccess; ++i) e = vp::qkvattn_launch(c->dtype, qa, nullptr, nullptr, 0);
+    hipEventRecord(e1, nullptr);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, e0, e1);
+    *ms_out = ms / iters;
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    if (e != hipSuccess) return dbg_finish(c, fail(c, VP_ERR_HIP, std::string("qkvattn bench: ") + hipGetErrorString(e)));
+    return dbg_finish(c, VP_OK);
+}
+#endif
+
 // LayerNorm(eps 1e-6): x [M,D] fp32 -> out16 (as fp32) [M,D] and out32 [M,D]
 VP_API int vp_dbg_layernorm(int32_t device, int32_t dtype, int32_t M, int32_t D, const float* x, const float* gamma,
                             const float* beta, float* out16, float* out32) {

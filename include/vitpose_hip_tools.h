@@ -23,6 +23,10 @@ VP_API int vp_dbg_gemm_timeline(int32_t device, int32_t dtype, int32_t epi, int3
 VP_API int vp_dbg_gemm8_timeline(int32_t device_id, int32_t dtype, int32_t epi, int32_t variant, int32_t flags, int32_t ablate,
                                  int32_t M, int32_t N, int32_t K, uint64_t* stamps, int32_t max_wg);
 
+/* tools/qkvattn_phases.py: average milliseconds per launch of the fused qkv + attention kernel (csrc/qkvattn.hip) on random operands; ablate bits:
+ * 1 = no attention phase, 2 = no epilogue (hand-over of q / k / v through LDS), 4 = K-loop cut to four K-tiles */
+VP_API int vp_dbg_qkvattn_bench(int32_t device_id, int32_t npairs, int32_t D, int32_t heads, int32_t iters, int32_t ablate, float* ms_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -38,7 +38,7 @@ CASES = [
     # variant, dataset, batch, oracle crops, {family: substring}
     ('h', 'wholebody', 128, 2, {'gemm_qkv': 'gemm8_kernel<F16, 0, G8<256>>', 'gemm_fc1': 'gemm8_kernel<F16, 1, G8<256>>',
                                  'gemm_fc2': 'gemm8_kernel<F16, 6, G8<256>>'}),
-    ('l', 'coco_25', 64, 2, {'gemm_qkv': 'gemm8_kernel<F16, 0, G8<256>>', 'gemm_fc1': 'gemm8_kernel<F16, 1, G8<256>>'}),
+    ('l', 'coco_25', 64, 2, {'gemm_qkv': 'qkvattn_kernel<F16>', 'gemm_fc1': 'gemm8_kernel<F16, 1, G8<256>>'}),   # qkv + attention fused: 32 pairs x 16 heads = 512 tiles, K = 1024
     ('s', 'coco', 256, 4, {'gemm_fc1': 'gemm8_kernel<F16, 1, G8<256>>'}),
 ]
 
