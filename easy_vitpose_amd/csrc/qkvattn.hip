@@ -29,9 +29,12 @@ struct QA {
     static constexpr int OFF_X0 = 0, OFF_X1 = XS, OFF_W0 = 2 * XS, OFF_W1 = 2 * XS + W0S;
     static constexpr int BUF = 2 * XS + W0S + W1S;       // 72 KiB
     static constexpr int RING = 2 * BUF;                 // 144 KiB
-    static constexpr int CROP = 3 * XS;                  // Q, K, V of one crop
+    // attention-phase layout: [Q0 | K0 | Q1 | K1 | V0 | V1] (crop 0 / 1 of the pair).  Q and K are dead once every wave has its S^T = K Q^T
+    // (all three query tiles of a wave are multiplied up front), and ring buffer 0 (X0, X1, W0, W1 of a K-tile = the first 72 KiB) lies inside
+    // Q0 | K0 | Q1, the X0 slot of buffer 1 is K1: the next tile's first K-tile streams in under the softmax and the P V products
     static constexpr int VSUB = 192 * 32;                // one [192 keys][16 d] V sub-tile
-    static_assert(2 * CROP == RING, "the attention phase reuses exactly the ring");
+    static constexpr int V_BASE = 4 * XS;
+    static_assert(6 * XS == RING && BUF <= 3 * XS && BUF + XS <= 4 * XS, "the attention phase reuses exactly the ring; buffer 0 + X0 of buffer 1 inside Q0 K0 Q1 K1");
 };
 
 __device__ __forceinline__ u32x2 lds_read_tr16(const char* p) {
@@ -42,8 +45,9 @@ __device__ __forceinline__ u32x2 lds_read_tr16(const char* p) {
 }
 }  // namespace
 
-template <class T, int QT>
+template <class T>
 __global__ __launch_bounds__(512, 2) void qkvattn_kernel(QkvAttnArgs g) {
+    constexpr int QT = 3;   // query tiles of a wave processed together in the attention phase (all of them: see QA)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -65,13 +69,14 @@ __global__ __launch_bounds__(512, 2) void qkvattn_kernel(QkvAttnArgs g) {
     const size_t r64 = (size_t)64 * K * 2;               // + 64 rows
     const char* xb = nullptr;
     const char* wb = nullptr;
-    int pair = 0, head = 0;
+    int pair = 0, head = 0;                               // of the tile whose accumulators / attention phase are live
+    int ipair = 0, ihead = 0;                             // of the ISSUE tile (xb / wb): one tile ahead once the prefetch inside the attention phase has run
     auto set_tile = [&](int t) {
         const int tile = tbase + t;
-        pair = tile / g.heads;
-        head = tile - pair * g.heads;
-        xb = (const char*)(g.x_hi + ((size_t)pair * 384 + wave * 8) * K);
-        wb = (const char*)(g.wh + ((size_t)head * 192 + wave * 8) * K);
+        ipair = tile / g.heads;
+        ihead = tile - ipair * g.heads;
+        xb = (const char*)(g.x_hi + ((size_t)ipair * 384 + wave * 8) * K);
+        wb = (const char*)(g.wh + ((size_t)ihead * 192 + wave * 8) * K);
     };
     auto issue = [&](int which, int B, int kt) {
         char* dst = smem + B * QA::BUF + wave * 1024;
@@ -180,6 +185,10 @@ __global__ __launch_bounds__(512, 2) void qkvattn_kernel(QkvAttnArgs g) {
     set_tile(t);
     ring_start();
     for (;;) {
+        pair = ipair;
+        head = ihead;
+        const bool has_next = t + nloc < tcnt;
+        bool prefetched = false;
 #pragma unroll
         for (int f = 0; f < 3; ++f)
 #pragma unroll
@@ -230,7 +239,7 @@ __global__ __launch_bounds__(512, 2) void qkvattn_kernel(QkvAttnArgs g) {
                 const int crop = j / 6;
                 const int row = wr * 96 + (j % 6) * 16 + frow_e;
                 const float2 st = stat[j];
-                char* cb_ = smem + crop * QA::CROP;
+                char* cb_ = smem + crop * 2 * QA::XS;                              // Q of this crop; K: + XS; V: V_BASE + crop * XS
                 const int rsw = (row >> 1) & 7;
 #pragma unroll
                 for (int f = 0; f < 3; ++f) {
@@ -239,7 +248,7 @@ __global__ __launch_bounds__(512, 2) void qkvattn_kernel(QkvAttnArgs g) {
                     for (int e = 0; e < 4; ++e) v[e] = ln_fold(acc[f][j][e], st.x, s4[f][e], st.y, b4[f][e]);
                     const u32x2 o = {pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3])};
                     if (f < 2) *(u32x2*)(cb_ + f * QA::XS + row * 128 + ((qk_slot ^ rsw) << 4) + qk_byte) = o;
-                    else *(u32x2*)(cb_ + 2 * QA::XS + v_sub * QA::VSUB + row * 32 + v_byte) = o;
+                    else *(u32x2*)(smem + QA::V_BASE + crop * QA::XS + v_sub * QA::VSUB + row * 32 + v_byte) = o;
                 }
             }
         }
@@ -248,9 +257,9 @@ __global__ __launch_bounds__(512, 2) void qkvattn_kernel(QkvAttnArgs g) {
         // ---------------- attention core (attention.hip, one query tile live at a time): waves 0-3 crop 0, waves 4-7 crop 1 ----------------
         if (!(VP_ABLATE(g) & 1)) {
             const int crop = wave >> 2, lw = wave & 3;
-            const char* Qs = smem + crop * QA::CROP;
+            const char* Qs = smem + crop * 2 * QA::XS;
             const char* Ks = Qs + QA::XS;
-            const char* Vs = Ks + QA::XS;
+            const char* Vs = smem + QA::V_BASE + crop * QA::XS;
             // lane coordinates through an empty asm: every address of this phase is then formed here, after the K-loop, instead of being
             // hoisted in front of the tile loop and kept live (= spilled) across 144 accumulator + 72 fragment registers
             int fr = frow, fg = lane >> 4;
@@ -281,6 +290,15 @@ __global__ __launch_bounds__(512, 2) void qkvattn_kernel(QkvAttnArgs g) {
 #pragma unroll
                         for (int tq_ = 0; tq_ < QT; ++tq_) s[tq_][kt] = mfma16<T>(kf, qf[tq_][kk], s[tq_][kt]);
                     }
+                // every wave has its scores: Q and K are dead.  The next tile's K-tile 0 (ring buffer 0) and the X0 slot of its K-tile 1 start
+                // streaming into their LDS space now, under the softmax and the P V products of this tile
+                __syncthreads();
+                if (has_next) {
+                    set_tile(t + nloc);
+                    issue(2, 0, 0); issue(0, 0, 0); issue(3, 0, 0); issue(1, 0, 0);
+                    issue(0, 1, 1);
+                    prefetched = true;
+                }
                 u32x4 pf[QT][6];
                 float inv_l[QT];
 #pragma unroll
@@ -345,11 +363,18 @@ __global__ __launch_bounds__(512, 2) void qkvattn_kernel(QkvAttnArgs g) {
                 }
             }
         }
-        if (t + nloc >= tcnt) break;
+        if (!has_next) break;
         t += nloc;
-        __syncthreads();    // every wave is done reading Q / K / V before the ring refills the LDS
-        set_tile(t);
-        ring_start();
+        __syncthreads();    // every wave is done reading V before the rest of the ring refills the LDS
+        if (prefetched) {   // K-tile 0 and X0 of K-tile 1 are on their way since the middle of the attention phase: W0, W1 of K-tile 1 complete ring_start's state
+            issue(2, 1, 1); issue(3, 1, 1);
+            wait_vm<6>();   // leaves X0 / W0 / W1 of K-tile 1 (this tile's output stores are older than any load the count lets pass)
+            bar();
+            if (wr) bar();
+        } else {
+            set_tile(t);
+            ring_start();
+        }
     }
 }
 
@@ -392,8 +417,7 @@ hipError_t qkvattn_launch(int dtype, const QkvAttnArgs& a, hipStream_t s, char* 
     int dev = 0;
     (void)hipGetDevice(&dev);
     const int di = dtype == DT_F16 ? 0 : 1;
-    static const int qt = [] { const char* e = getenv("VP_QA_QT"); return e && atoi(e) == 1 ? 1 : 3; }();   // A/B of the attention phase's two forms (both bit-identical)
-    auto kern = dtype == DT_F16 ? (qt == 1 ? qkvattn_kernel<F16, 1> : qkvattn_kernel<F16, 3>) : (qt == 1 ? qkvattn_kernel<BF16, 1> : qkvattn_kernel<BF16, 3>);
+    auto kern = dtype == DT_F16 ? qkvattn_kernel<F16> : qkvattn_kernel<BF16>;
     if (dev < 0 || dev >= 64 || !attr_done[di][dev]) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, QA::RING);
         if (e != hipSuccess) return e;

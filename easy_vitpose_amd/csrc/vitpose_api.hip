@@ -622,7 +622,8 @@ int forward_chunk(vp_ctx* c, const void* d_crops, int fmt, int n, bool want_toke
             LnFuse cq; cq.rowstat = c->rowstat; cq.ln_s = b.s_qkv; cq.reverse = (c->order_mask & 1) != 0; cq.out_blocked = qkv_blocked;
             if (fold_stats) { cq.rowstat = nullptr; cq.ln_part = c->ln_part; cq.ln_tiles = D / 64; }
             // attn.qkv + attention core as ONE kernel per (pair of crops, head) once every CU gets >= 2 tiles (qkvattn.hip; bit-identical y)
-            if (b.w_qkvh && !fold_stats && (n & 1) == 0 && (long)(n / 2) * c->heads >= 512 && c->gemm_variant[VP_PROF_GEMM_QKV] < 0) {
+            static const long qa_min_tiles = [] { const char* e = getenv("VP_QA_MIN_TILES"); return e ? atol(e) : 512L; }();   // measured sweep: profiles/qkvattn_r4.txt
+            if (b.w_qkvh && !fold_stats && (n & 1) == 0 && (long)(n / 2) * c->heads >= qa_min_tiles && c->gemm_variant[VP_PROF_GEMM_QKV] < 0) {
                 vp::QkvAttnArgs qa{};
                 qa.x_hi = xh; qa.wh = b.w_qkvh; qa.bh = b.b_qkvh; qa.sh = b.s_qkvh; qa.rowstat = c->rowstat; qa.y = c->y;
                 qa.npairs = n / 2; qa.heads = c->heads; qa.D = D;
