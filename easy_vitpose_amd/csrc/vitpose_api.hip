@@ -99,7 +99,7 @@ struct vp_ctx {
     bool blocked_hid = true;          // mlp hidden activations in the 64x64-blocked layout (VP_BLOCKED_HID=0: row-major)
     bool blocked_qkv = true;          // qkv in the same blocked layout when the head dim is 64 (a (crop, head) slab = three contiguous 8 KiB blocks; VP_BLOCKED_QKV=0: row-major)
     bool fuse_ln = true;              // LayerNorm folded into the GEMMs on both sides of it (VP_FUSE_LN=0: standalone passes)
-    bool fuse_qkv_attn = true;        // head dim 64, even batches of >= 2 tiles per CU: attn.qkv + attention core in one kernel (VP_FUSE_QKV_ATTN=0: two launches)
+    bool fuse_qkv_attn = true;        // head dim 64, even batches of >= 128 (pair, head) tiles: attn.qkv + attention core in one kernel (VP_FUSE_QKV_ATTN=0: two launches)
     float *ln_part = nullptr, *rowstat = nullptr;   // partial row statistics [M][D/64][2], (mean, rstd) [M][2]
     // fp8 mode (vp_config.dtype = VP_DTYPE_FP8; csrc/mx8.h, gemm8f.hip, quant8.hip): qkv / fc1 / fc2 on MXFP8 operands.  Token rows are
     // padded to Mp (a multiple of the 256-row GEMM tile, >= 512); x8 / xs8 = LayerNorm(x) as MXFP8 codes / scales, hs8 = block scales of
@@ -621,8 +621,8 @@ int forward_chunk(vp_ctx* c, const void* d_crops, int fmt, int n, bool want_toke
             const Block& b = c->blocks[l];
             LnFuse cq; cq.rowstat = c->rowstat; cq.ln_s = b.s_qkv; cq.reverse = (c->order_mask & 1) != 0; cq.out_blocked = qkv_blocked;
             if (fold_stats) { cq.rowstat = nullptr; cq.ln_part = c->ln_part; cq.ln_tiles = D / 64; }
-            // attn.qkv + attention core as ONE kernel per (pair of crops, head) once every CU gets >= 2 tiles (qkvattn.hip; bit-identical y)
-            static const long qa_min_tiles = [] { const char* e = getenv("VP_QA_MIN_TILES"); return e ? atol(e) : 512L; }();   // measured sweep: profiles/qkvattn_r4.txt
+            // attn.qkv + attention core as ONE kernel per (pair of crops, head) for even batches of >= 128 tiles (qkvattn.hip; bit-identical y)
+            static const long qa_min_tiles = [] { const char* e = getenv("VP_QA_MIN_TILES"); return e ? atol(e) : 128L; }();   // the fused kernel wins from 128 tiles on (measured sweep 128 - 1536 tiles: profiles/qkvattn_r4.txt)
             if (b.w_qkvh && !fold_stats && (n & 1) == 0 && (long)(n / 2) * c->heads >= qa_min_tiles && c->gemm_variant[VP_PROF_GEMM_QKV] < 0) {
                 vp::QkvAttnArgs qa{};
                 qa.x_hi = xh; qa.wh = b.w_qkvh; qa.bh = b.b_qkvh; qa.sh = b.s_qkvh; qa.rowstat = c->rowstat; qa.y = c->y;
