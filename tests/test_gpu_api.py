@@ -93,6 +93,7 @@ def test_small_batch_graph_replay_is_bit_identical(monkeypatch):
 def test_blocked_qkv_layout_is_bit_identical(monkeypatch, variant, dataset, dtype, n):
     """Head dim 64: the qkv GEMM writes its output in the 64 x 64-blocked layout and the attention kernel reads a (crop, head)'s q / k / v as three
     contiguous 8 KiB blocks (VP_BLOCKED_QKV, default on).  Only addresses change: heatmaps and keypoints agree bit for bit with the row-major layout."""
+    monkeypatch.setenv('VP_FUSE_QKV_ATTN', '0')   # the fused qkv + attention kernel never materialises qkv: this test is about the layout of that tensor
     shp, sd, _ = weights(variant, dataset)
     crops = synthetic_crops(n, 17, 'blobs')
     monkeypatch.setenv('VP_BLOCKED_QKV', '0')
@@ -169,6 +170,7 @@ def test_mid_batch_gemm8_selection_is_bit_identical(monkeypatch, n):
     shp, sd, _ = weights('b', 'coco')
     crops = synthetic_crops(n, 41, 'blobs')
     fams = ('gemm_qkv', 'gemm_fc1', 'gemm_fc2')
+    monkeypatch.setenv('VP_FUSE_QKV_ATTN', '0')   # keep attn.qkv a GEMM of its own here (the fused qkv + attention kernel has its own test)
     monkeypatch.setenv('VP_GEMM8', '0')           # a PRODUCT-side switch (vp_create): every GEMM on the 2-phase kernels
     eng = VitPoseHip(shp, sd, dtype='fp16', max_batch=n)
     ref_kp, ref_tok = eng.infer(crops), eng.tokens(crops)

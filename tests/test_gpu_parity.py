@@ -329,6 +329,8 @@ def test_persistent_gemm_is_bit_identical(monkeypatch):
     shp, sd, _ = weights('b', 'coco')
     crops = synthetic_crops(64, 21, 'noise')          # 64 x 18 = 1152 qkv tiles, 1536 fc1 tiles
     out = {}
+    monkeypatch.setenv('VP_FUSE_QKV_ATTN', '0')       # attn.qkv as a GEMM of its own (otherwise the fused qkv + attention kernel takes it at this size)
+    monkeypatch.setenv('VP_GEMM8', '0')               # and on the 2-phase kernels, where the persistent variant lives
     for flag in ('0', '1'):
         monkeypatch.setenv('VP_PERSIST', flag)
         eng = VitPoseHip(shp, sd, dtype='fp16', max_batch=64)
