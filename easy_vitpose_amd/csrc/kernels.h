@@ -147,13 +147,14 @@ hipError_t attention_launch(int dtype, const uint16_t* qkv, uint16_t* out, int B
 // wh / bh / sh = head-major copies of the LayerNorm-folded qkv weights / bias / row sums (qkv_head_major_launch).  y bit-identical to
 // gemm (EPI_BIAS, LayerNorm-consumer fold) + attention_launch.
 struct QkvAttnArgs {
-    const uint16_t* x_hi;     // hi plane of the residual stream [2 npairs 192, D] (un-normalised 16-bit rows)
+    const uint16_t* x_hi;     // hi plane of the residual stream [ncrops 192, D] (un-normalised 16-bit rows)
     const uint16_t* wh;       // [heads 192, D]
     const float* bh;          // [heads 192]
     const float* sh;          // [heads 192]
     const float* rowstat;     // (mean, rstd) per token row
-    uint16_t* y;              // attention output [2 npairs 192, D]
+    uint16_t* y;              // attention output [ncrops 192, D]
     int npairs, heads, D;
+    int ncrops;               // 2 npairs, or 2 npairs - 1: the last pair of an odd batch runs its only crop in both halves (identical results stored twice)
     float scale_log2e;        // head_dim^-0.5 * log2(e)
     int ablate;               // VP_TOOLS builds only (tools/qkvattn_phases.py): 1 = no attention phase, 2 = no epilogue (LDS hand-over), 4 = no K-loop, 8 = no ring restart wait
 };

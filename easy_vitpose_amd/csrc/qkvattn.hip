@@ -69,6 +69,7 @@ __global__ __launch_bounds__(512, 2) void qkvattn_kernel(QkvAttnArgs g) {
     const size_t r64 = (size_t)64 * K * 2;               // + 64 rows
     const char* xb = nullptr;
     const char* wb = nullptr;
+    size_t xb1off = 0;                                    // byte offset of the pair's second crop from its first (0 when an odd batch's last crop stands in for it)
     int pair = 0, head = 0;                               // of the tile whose accumulators / attention phase are live
     int ipair = 0, ihead = 0;                             // of the ISSUE tile (xb / wb): one tile ahead once the prefetch inside the attention phase has run
     auto set_tile = [&](int t) {
@@ -76,6 +77,8 @@ __global__ __launch_bounds__(512, 2) void qkvattn_kernel(QkvAttnArgs g) {
         ipair = tile / g.heads;
         ihead = tile - ipair * g.heads;
         xb = (const char*)(g.x_hi + ((size_t)ipair * 384 + wave * 8) * K);
+        // odd batch: the last pair's second half is the last crop once more (same inputs, same arithmetic, the same bytes stored twice)
+        xb1off = (2 * ipair + 1 < g.ncrops) ? (size_t)192 * K * 2 : 0;
         wb = (const char*)(g.wh + ((size_t)ihead * 192 + wave * 8) * K);
     };
     auto issue = [&](int which, int B, int kt) {
@@ -83,7 +86,7 @@ __global__ __launch_bounds__(512, 2) void qkvattn_kernel(QkvAttnArgs g) {
         uint32_t v = voff;
         asm volatile("" : "+v"(v));                       // addresses formed at their use (gemm8.hip: no pointers kept live across the sections)
         if (which < 2) {   // X half = crop `which` of the pair
-            const char* src = xb + ((size_t)which * 192 * K + (size_t)kt * 64) * 2 + v;
+            const char* src = xb + (which ? xb1off : 0) + (size_t)kt * 128 + v;
             glds16(src, dst + which * QA::XS);
             glds16(src + r64, dst + which * QA::XS + 8192);
             glds16(src + 2 * r64, dst + which * QA::XS + 16384);
@@ -217,6 +220,7 @@ __global__ __launch_bounds__(512, 2) void qkvattn_kernel(QkvAttnArgs g) {
             b4[f] = *(const f32x4*)(g.bh + c);
             s4[f] = *(const f32x4*)(g.sh + c);
         }
+        const bool twin = 2 * pair + 1 >= g.ncrops;                                   // odd batch, last pair: its second half IS its first crop
         const float* rs0 = g.rowstat + 2 * ((size_t)pair * 384 + wr * 96 + frow_e);   // crop 0 of the pair; crop 1: + 2 * 192 floats
 #pragma unroll
         for (int j = 0; j < 6; ++j) stat[j] = *(const float2*)(rs0 + 32 * j);          // crop 1's six follow inside the epilogue, under crop 0's stores
@@ -233,7 +237,7 @@ __global__ __launch_bounds__(512, 2) void qkvattn_kernel(QkvAttnArgs g) {
             const int v_byte = ((wc & 1) * 2 + (fg_e >> 1)) * 8;
             (void)dcol;
 #pragma unroll
-            for (int j = 6; j < 12; ++j) stat[j] = *(const float2*)(rs0 + 384 + 32 * (j - 6));
+            for (int j = 6; j < 12; ++j) stat[j] = *(const float2*)(rs0 + (twin ? 0 : 384) + 32 * (j - 6));
 #pragma unroll
             for (int j = 0; j < 12; ++j) {
                 const int crop = j / 6;
@@ -267,7 +271,7 @@ __global__ __launch_bounds__(512, 2) void qkvattn_kernel(QkvAttnArgs g) {
             const char* kfrag = Ks + fr * 128;
             const int kswz = (fr >> 1) & 7;
             const char* vfrag = Vs + (fg * 4 + (fr >> 2)) * 32 + (fr & 3) * 8;
-            const size_t b = (size_t)pair * 2 + crop;
+            const size_t b = (size_t)pair * 2 + ((2 * pair + 1 < g.ncrops) ? crop : 0);
             // QT query tiles of the wave at a time.  QT = 3 (the accumulators are dead: 256 registers for this phase): every K / V^T fragment read from
             // LDS feeds three MFMAs; QT = 1: attention.hip's shipped form.  Per query tile the arithmetic is attention.hip's, instruction for instruction.
 #pragma unroll
@@ -403,7 +407,7 @@ hipError_t qkv_head_major_launch(const uint16_t* w, const float* b, const float*
 }
 
 bool qkvattn_supported(const QkvAttnArgs& a) {
-    if (a.D % 128 || a.D < 256 || a.heads * 64 != a.D || a.npairs <= 0) return false;
+    if (a.D % 128 || a.D < 256 || a.heads * 64 != a.D || a.npairs <= 0 || (a.ncrops != 2 * a.npairs && a.ncrops != 2 * a.npairs - 1)) return false;
     if ((size_t)a.npairs * 384 * a.D * 2 >= (1ull << 32)) return false;   // 32-bit per-lane offsets are relative to the tile base: only the row span matters; kept conservative
     return a.npairs * a.heads >= 8;
 }

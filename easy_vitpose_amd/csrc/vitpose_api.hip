@@ -621,12 +621,12 @@ int forward_chunk(vp_ctx* c, const void* d_crops, int fmt, int n, bool want_toke
             const Block& b = c->blocks[l];
             LnFuse cq; cq.rowstat = c->rowstat; cq.ln_s = b.s_qkv; cq.reverse = (c->order_mask & 1) != 0; cq.out_blocked = qkv_blocked;
             if (fold_stats) { cq.rowstat = nullptr; cq.ln_part = c->ln_part; cq.ln_tiles = D / 64; }
-            // attn.qkv + attention core as ONE kernel per (pair of crops, head) for even batches of >= 128 tiles (qkvattn.hip; bit-identical y)
+            // attn.qkv + attention core as ONE kernel per (pair of crops, head) from 128 tiles on (qkvattn.hip; bit-identical y; an odd batch's last crop fills both halves of its pair)
             static const long qa_min_tiles = [] { const char* e = getenv("VP_QA_MIN_TILES"); return e ? atol(e) : 128L; }();   // the fused kernel wins from 128 tiles on (measured sweep 128 - 1536 tiles: profiles/qkvattn_r4.txt)
-            if (b.w_qkvh && !fold_stats && (n & 1) == 0 && (long)(n / 2) * c->heads >= qa_min_tiles && c->gemm_variant[VP_PROF_GEMM_QKV] < 0) {
+            if (b.w_qkvh && !fold_stats && (long)((n + 1) / 2) * c->heads >= qa_min_tiles && c->gemm_variant[VP_PROF_GEMM_QKV] < 0) {
                 vp::QkvAttnArgs qa{};
                 qa.x_hi = xh; qa.wh = b.w_qkvh; qa.bh = b.b_qkvh; qa.sh = b.s_qkvh; qa.rowstat = c->rowstat; qa.y = c->y;
-                qa.npairs = n / 2; qa.heads = c->heads; qa.D = D;
+                qa.npairs = (n + 1) / 2; qa.ncrops = n; qa.heads = c->heads; qa.D = D;   // odd n: the last crop fills both halves of its pair
                 const float scale = 1.0f / sqrtf(64.0f);
                 qa.scale_log2e = scale * 1.4426950408889634f;
                 char desc[96];
@@ -1583,7 +1583,7 @@ VP_API int vp_dbg_qkvattn(int32_t device, int32_t dtype, int32_t npairs, int32_t
         return dbg_finish(c, rc);
     hipError_t e = vp::qkv_head_major_launch(dw, db, ds, dwh, dbh, dsh, D, D, nullptr);
     vp::QkvAttnArgs qa{};
-    qa.x_hi = dx; qa.wh = dwh; qa.bh = dbh; qa.sh = dsh; qa.rowstat = drow; qa.y = dy; qa.npairs = npairs; qa.heads = heads; qa.D = D;
+    qa.x_hi = dx; qa.wh = dwh; qa.bh = dbh; qa.sh = dsh; qa.rowstat = drow; qa.y = dy; qa.npairs = npairs; qa.ncrops = 2 * npairs; qa.heads = heads; qa.D = D;
     const float scale = 1.0f / sqrtf(64.0f);
     qa.scale_log2e = scale * 1.4426950408889634f;
     if (e == hipSuccess && !vp::qkvattn_supported(qa)) return dbg_finish(c, fail(c, VP_ERR_INVALID, "shape not supported by the fused qkv + attention kernel"));
@@ -1609,7 +1609,7 @@ VP_API int vp_dbg_qkvattn_bench(int32_t device, int32_t npairs, int32_t D, int32
     vp::fill_random16(c->dtype, dwh, 3 * (size_t)D * D, 2u, nullptr);
     hipMemset(dbh, 0, 3 * (size_t)D * 4); hipMemset(dsh, 0, 3 * (size_t)D * 4); hipMemset(drow, 0, 2 * M * 4);
     vp::QkvAttnArgs qa{};
-    qa.x_hi = dx; qa.wh = dwh; qa.bh = dbh; qa.sh = dsh; qa.rowstat = drow; qa.y = dy; qa.npairs = npairs; qa.heads = heads; qa.D = D; qa.ablate = ablate;
+    qa.x_hi = dx; qa.wh = dwh; qa.bh = dbh; qa.sh = dsh; qa.rowstat = drow; qa.y = dy; qa.npairs = npairs; qa.ncrops = 2 * npairs; qa.heads = heads; qa.D = D; qa.ablate = ablate;
     qa.scale_log2e = 0.125f * 1.4426950408889634f;
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);

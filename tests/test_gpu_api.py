@@ -189,7 +189,8 @@ def test_mid_batch_gemm8_selection_is_bit_identical(monkeypatch, n):
     assert np.array_equal(kp, ref_kp)
 
 
-@pytest.mark.parametrize('variant,dataset,dtype,n', [('b', 'coco', 'fp16', 96), ('l', 'coco_25', 'fp16', 64), ('b', 'coco', 'bf16', 128), ('b', 'coco', 'fp16', 256)])
+@pytest.mark.parametrize('variant,dataset,dtype,n', [('b', 'coco', 'fp16', 96), ('l', 'coco_25', 'fp16', 64), ('b', 'coco', 'bf16', 128), ('b', 'coco', 'fp16', 256),
+                                                     ('l', 'coco_25', 'fp16', 16), ('b', 'coco', 'fp16', 23)])   # 16: replayed from a hipGraph; 23: odd, 144 tiles
 def test_fused_qkv_attention_is_bit_identical(monkeypatch, variant, dataset, dtype, n):
     """attn.qkv + the attention core in one kernel per (pair of crops, head) (qkvattn.hip: 384 x 192 tiles on the 8-phase schedule, q / k / v handed
     to the attention core through LDS, the [M, 3D] tensor never in HBM) against the two-launch path (VP_FUSE_QKV_ATTN=0): same accumulation order,
@@ -207,8 +208,10 @@ def test_fused_qkv_attention_is_bit_identical(monkeypatch, variant, dataset, dty
     eng = VitPoseHip(shp, sd, dtype=dtype, max_batch=n)
     runs = [(eng.infer(crops), eng.tokens(crops)) for _ in range(3)]
     kernel = eng.profile_kernel('gemm_qkv')
-    odd = eng.infer(crops[:n - 1])                      # an odd batch takes the two-launch path
+    odd = eng.infer(crops[:n - 1])                      # an odd batch: the last crop fills both halves of its pair
+    odd_kernel = eng.profile_kernel('gemm_qkv')
     eng.close()
+    assert 'qkvattn_kernel' in odd_kernel
     print(f'[{variant}/{dtype} @ {n}] qkv family: {ref_kernel!r} vs {kernel!r}')
     assert 'qkvattn_kernel' in kernel and 'qkvattn_kernel' not in ref_kernel
     for kp, tok in runs:
