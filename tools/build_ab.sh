@@ -9,6 +9,6 @@ python -c "from easy_vitpose_amd.build import build_library; build_library()"
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -ffp-contract=fast -Wno-unused-result $DEFS \
   -Rpass-analysis=kernel-resource-usage -c easy_vitpose_amd/csrc/$SRC -o $L/ab/$NAME.o 2> $L/ab/$NAME.log
 echo -n "$NAME VGPRs / spills: "; grep -E "VGPRs:|VGPRs Spill" $L/ab/$NAME.log | awk '{printf "%s ", $(NF-1)}'; echo
-OBJS=""; for s in gemm gemm8 attention elementwise decode fp8_probe vitpose_api; do
+OBJS=""; for s in $(python -c "from easy_vitpose_amd.build import SOURCES; print(' '.join(x[:-4] for x in SOURCES))"); do
   if [ $s.hip = $SRC ]; then OBJS="$OBJS $L/ab/$NAME.o"; else OBJS="$OBJS $L/$s.o"; fi; done
 hipcc --offload-arch=gfx950 -shared -fPIC $OBJS -o $L/ab/$NAME.so
