@@ -155,7 +155,18 @@ __global__ __launch_bounds__(C::NT, 2) void gemm_kernel(GemmArgs g) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tiles_n = (g.N + C::BN - 1) / C::BN;
     const int tiles_m = (g.M + C::BM - 1) / C::BM;
-    int bid = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+    // deconv: the four output parities of a tile are four CONSECUTIVE logical blocks (they read the same input rows, shifted by a tap): with
+    // the XCD remap they run side by side on one XCD and share those rows in its L2 (parity on blockIdx.y ran all tiles of parity 0
+    // first: every parity fetched the activations again)
+    int bid, parity = 0;
+    if (AMODE == A_DECONV && g.parity_fast) {
+        const int lb = xcd_remap(blockIdx.x, tiles_m * tiles_n * 4);
+        parity = lb & 3;
+        bid = lb >> 2;
+    } else {
+        bid = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+        if (AMODE == A_DECONV) parity = blockIdx.y;
+    }
     if (g.reverse) bid = tiles_m * tiles_n - 1 - bid;   // walk the tiles last-to-first: start with what the producer wrote last
     int tm, tn;
     if (g.group_m > 1) {   // grouped order: GROUP_M m-tiles x all n-tiles, m fastest inside the group
@@ -170,7 +181,6 @@ __global__ __launch_bounds__(C::NT, 2) void gemm_kernel(GemmArgs g) {
         tn = bid - tm * tiles_n;
     }
     const int n0 = tn * C::BN, m0 = tm * C::BM;
-    const int parity = (AMODE == A_DECONV) ? blockIdx.y : 0;
     const int K = g.K;
 
     // ---- staging addresses: piece p of an operand = rows [(p*NWAVES + wave)*RPG, +RPG) ----
@@ -1184,7 +1194,7 @@ static hipError_t launch(const GemmArgs& a, hipStream_t s) {
     g.w_parity_stride = (size_t)a.w_rows * a.K;
     if ((size_t)tiles_n * C::BN > (size_t)a.w_rows) return hipErrorInvalidValue;   // weight rows are padded at upload
     const int tiles = ((a.M + C::BM - 1) / C::BM) * tiles_n;
-    dim3 grid(tiles, AMODE == A_DECONV ? 4 : 1);
+    dim3 grid(AMODE == A_DECONV && a.parity_fast ? tiles * 4 : tiles, AMODE == A_DECONV && !a.parity_fast ? 4 : 1);
     if (a.desc)
         snprintf(a.desc, a.desc_cap, "gemm_kernel<%s, %d, %d, TileCfg<%d, %d, %d, %d, %d, %d, %d, %d>>", std::is_same<T, F16>::value ? "F16" : "BF16", EPI,
                  AMODE, C::BM, C::BN, C::BK, C::WM, C::WN, C::STAGES, C::PIPE, C::DIRECT);

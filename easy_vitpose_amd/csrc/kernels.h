@@ -89,6 +89,7 @@ struct GemmArgs {
     // ---- fp8 mode (gemm8f.hip; csrc/mx8.h): A = MXFP8 codes in 64 x 128 blocks (at `A`) + packed E8M0 block scales, W = e4m3 codes
     // row-major [w_rows, K] (at `W`) + one fp32 scale per output channel; EPI_BIAS_GELU writes its output as MXFP8 (codes at `out`, K of the
     // consumer = ldo, scales at out_scales)
+    int parity_fast;   // deconv: 1 = the four output parities of a tile are consecutive logical blocks (same XCD, shared input rows); 0 = parity on blockIdx.y
     const uint8_t* a_scales;
     const float* w_scale;
     uint8_t* out_scales;

@@ -96,6 +96,23 @@ def peaked_crops(n: int):
     return np.concatenate([synthetic_crops(n // 2, 21, 'blobs'), synthetic_crops(n - n // 2, 22, 'noise')])
 
 
+def fullbatch_plan():
+    """(variant, dataset, crops) of the full-batch goldens = the BASELINE configurations at their own batch sizes:
+    configs[1] b/coco 256, configs[2] h/wholebody 128, configs[3] l/coco_25 64 (one frame of 64 persons), configs[4] b/ap10k 512, and
+    s/coco at 256 (configs[0]'s model at a production batch)."""
+    # (ascending keypoint count: the reference's config modules share one dict, a K = 17 model built after the K = 133 one keeps 133)
+    return [('s', 'coco', 256), ('b', 'coco', 256), ('b', 'ap10k', 512), ('l', 'coco_25', 64), ('h', 'wholebody', 128)]
+
+
+def fullbatch_crops(n: int):
+    """Half blob crops, half uniform-noise crops (seeds 41 / 42), interleaved so that every chunk of the batch holds both kinds."""
+    from easy_vitpose_amd.synth import synthetic_crops
+    a, b = synthetic_crops(n // 2, 41, 'blobs'), synthetic_crops(n - n // 2, 42, 'noise')
+    out = np.empty((n,) + a.shape[1:], a.dtype)
+    out[0::2], out[1::2] = b, a
+    return out
+
+
 def tracker_sequence():
     """Detections [n, 5] (x1, y1, x2, y2, score) per frame for the tracker golden: three people walking (one of them missed by
     the detector on two frames), a fourth entering at frame 6, two crossing paths, and detector-skipped (empty) frames as

@@ -2,7 +2,7 @@
 """Generate the golden fixtures by running THE REFERENCE ITSELF in this container.
 
     python tests/golden/make_golden.py            # writes tests/golden/*.npz
-    python tests/golden/make_golden.py --only=tracker,outlier     # sections: caller decode model tracker peaked outlier
+    python tests/golden/make_golden.py --only=tracker,outlier     # sections: caller decode model tracker peaked outlier fullbatch
 
 Runs only where ``/root/reference`` exists (the build container).  The reference
 package is imported read-only with ``sys.dont_write_bytecode`` and with empty stub
@@ -321,6 +321,25 @@ def main():
                   f'{kps[..., 2].max():.3f}, oracle-vs-reference keypoints max|d| = {np.abs(mine - kps).max():.3e}')
             np.savez_compressed(os.path.join(HERE, f'peaked_outlier_{variant}_{dataset}.npz'), variant=variant, dataset=dataset, n=n,
                                 keypoints=kps, heatmaps0=hm0[:, :16].astype(np.float32))
+
+    # ------------------------------------------------------- full-batch goldens
+    # The BASELINE configurations at their own batch sizes, peaked checkpoint, EVERY crop through the reference's own per-crop path
+    # (`VitInference._inference_torch`): the device's 256- / 128- / 64- / 512-crop batches are compared joint by joint with these.
+    # (minutes of CPU time: ViTPose-H is ~1 s per crop here)
+    if want('fullbatch'):
+        import time
+        from cases import fullbatch_plan, fullbatch_crops
+        for variant, dataset, n in fullbatch_plan():
+            shp = model_shape(variant, dataset)
+            sd = synthetic_state_dict(shp, seed=0, peaked=True)
+            V = build_ref(VitInference, ViTPose, dyn_model_import, dataset, variant, sd)
+            crops = fullbatch_crops(n)
+            t0 = time.time()
+            with torch.no_grad():
+                kps = np.concatenate([V._inference_torch(crops[i]) for i in range(n)], 0).astype(np.float32)
+            print(f'full batch {variant}/{dataset}: {n} crops x {shp.num_keypoints} joints through the reference in {time.time() - t0:.0f} s, '
+                  f'confidences {kps[..., 2].min():.3f} .. {kps[..., 2].max():.3f}', flush=True)
+            np.savez_compressed(os.path.join(HERE, f'full_{variant}_{dataset}_{n}.npz'), variant=variant, dataset=dataset, n=n, keypoints=kps)
 
 
 if __name__ == '__main__':

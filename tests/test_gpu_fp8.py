@@ -210,6 +210,26 @@ def test_fp8_mode_config5_batch512():
     assert rms < FP8_HM_RMS_NOISE
 
 
+def test_fp8_mode_config5_full_batch_against_the_reference(golden_dir):
+    """BASELINE configs[4] as written (ViTPose-B / AP-10K, 512 crops in one call, fp8 operands), peaked checkpoint, EVERY crop and joint against the
+    keypoints the reference produced crop by crop (tests/golden/full_b_ap10k_512.npz): coordinates inside the north_star's +-0.5 px, confidences
+    at the mode's own measured bound (NOT the north_star's 1e-3)."""
+    import os
+    from cases import fullbatch_crops
+    z = np.load(os.path.join(golden_dir, 'full_b_ap10k_512.npz'))
+    shp = model_shape('b', 'ap10k')
+    eng = VitPoseHip(shp, synthetic_state_dict(shp, 0, peaked=True), dtype='fp8', device_id=0, max_batch=512)
+    kp = eng.infer(fullbatch_crops(512))
+    eng.close()
+    ref = z['keypoints']
+    dpx = np.abs(kp[..., :2] - ref[..., :2]).max(-1)
+    dcf = np.abs(kp[..., 2] - ref[..., 2])
+    print(f'[fp8 mode, b/ap10k x 512 vs the reference] {dpx.size} joints: coordinate max err {dpx.max():.4f} px; confidence max err {dcf.max():.3e} '
+          f'rms {np.sqrt((dcf ** 2).mean()):.3e}, {(dcf < CONF_TOL).mean():.3f} within 1e-3')
+    assert np.isfinite(kp).all() and dpx.max() < KP_TOL_PX
+    assert dcf.max() < FP8_CONF_ERR_PEAKED
+
+
 def test_fp8_mode_rejects_what_it_does_not_support():
     shp, sd, _ = weights('s', 'coco')
     with pytest.raises(Exception):

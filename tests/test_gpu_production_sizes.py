@@ -200,6 +200,34 @@ def test_attention_at_production_block_counts(B, D, heads):
 
 
 # ------------------------------------------------------------------ noise-map confidence statistic, tightened
+def _fullbatch_cases():
+    from cases import fullbatch_plan
+    return fullbatch_plan()
+
+
+@pytest.mark.parametrize('variant,dataset,n', _fullbatch_cases(), ids=[f'{v}-{d}-{n}' for v, d, n in _fullbatch_cases()])
+def test_full_batch_against_the_reference_itself(golden_dir, variant, dataset, n):
+    """every BASELINE configuration at ITS OWN batch size (256 / 512 / 64 / 128 crops in one call), every crop and
+    every joint against the keypoints the reference produced crop by crop in the build container (tests/golden/full_*.npz,
+    make_golden.py --only=fullbatch; peaked checkpoint = well-conditioned maps): +-0.5 px and 1e-3, the north_star's tolerances."""
+    from cases import fullbatch_crops
+    z = np.load(os.path.join(golden_dir, f'full_{variant}_{dataset}_{n}.npz'))
+    assert int(z['n']) == n
+    shp = model_shape(variant, dataset)
+    eng = VitPoseHip(shp, synthetic_state_dict(shp, 0, peaked=True), dtype='fp16', device_id=0, max_batch=n)
+    kp = eng.infer(fullbatch_crops(n))
+    kernels = {f: eng.profile_kernel(f) for f in ('gemm_qkv', 'gemm_fc1', 'gemm_fc2', 'gemm_proj')}
+    eng.close()
+    ref = z['keypoints']
+    assert kp.shape == ref.shape == (n, shp.num_keypoints, 3) and np.isfinite(kp).all()
+    dpx = np.abs(kp[..., :2] - ref[..., :2]).max(-1)
+    dcf = np.abs(kp[..., 2] - ref[..., 2])
+    print(f'[full batch {variant}/{dataset} x {n} vs the reference] {dpx.size} joints: coordinate max err {dpx.max():.4f} px (mean {dpx.mean():.5f}), '
+          f'confidence max err {dcf.max():.3e} (rms {np.sqrt((dcf ** 2).mean()):.3e}); kernels {kernels}')
+    assert dpx.max() < KP_TOL_PX
+    assert dcf.max() < CONF_TOL
+
+
 def test_noise_map_confidence_statistic_vitpose_h():
     """Random-weight heatmaps are full-scale noise (std 0.3, maxima ~1): with 16-bit operands the error at the arg-max is
     ~N(0, 3.3e-4) on the 32-block model, so 1e-3 is a 3-sigma event per joint and `every joint < 1e-3` is not a property of the
