@@ -144,11 +144,11 @@ def test_library_loads_and_exports_every_header_symbol():
 
 def test_tools_library_exports_the_measurement_entry_points():
     """include/vitpose_hip_tools.h = the -DVP_TOOLS build of the same sources (tools/ only): it exports everything the product
-    header declares plus the timeline taps; the PRODUCT library does not carry those."""
+    header declares plus the timeline taps and the fused-kernel timing loop; the PRODUCT library does not carry those."""
     from easy_vitpose_amd.build import build_library, TOOLS_LIB
     hdr = open(os.path.join(ROOT, 'include', 'vitpose_hip_tools.h')).read()
     tools_only = sorted(set(re.findall(r'VP_API\s+[\w\s\*]+?\b(vp_\w+)\s*\(', hdr)))
-    assert tools_only == ['vp_dbg_gemm8_timeline', 'vp_dbg_gemm_timeline']
+    assert tools_only == ['vp_dbg_gemm8_timeline', 'vp_dbg_gemm_timeline', 'vp_dbg_qkvattn_bench']
     tl = C.CDLL(build_library(tools=True))
     assert os.path.samefile(TOOLS_LIB, tl._name)
     for name in tools_only + list(capi.SYMBOLS):
