@@ -1253,23 +1253,23 @@ static hipError_t dispatch(int epi, const GemmArgs& a, hipStream_t s) {
 int gemm_tile_bn(int variant) {
     static const int bn[NUM_TILE_CFGS] = {Cfg0::BN, Cfg1::BN, Cfg2::BN, Cfg3::BN, Cfg4::BN, Cfg5::BN, Cfg6::BN, Cfg7::BN, Cfg8::BN, Cfg9::BN, Cfg10::BN, Cfg11::BN,
                                           Cfg12::BN, Cfg13::BN, Cfg14::BN, Cfg15::BN};
-    if (variant == 16 || variant == 19) return 256;
+    if (variant == 16 || variant == 18 || variant == 19) return 256;
     if (variant == 17) return 192;
     return (variant >= 0 && variant < NUM_TILE_CFGS) ? bn[variant] : 0;
 }
 
 hipError_t gemm_launch(int dtype, int epi, const GemmArgs& a, hipStream_t s) {
     if (a.K % 64 != 0 || a.M <= 0 || a.N <= 0) return hipErrorInvalidValue;
-    if (a.variant == 16 || a.variant == 17 || a.variant == 19) {
+    if (a.variant >= 16 && a.variant <= 19) {   // 16: 256 x 256, 17: 256 x 192, 18: 192 x 256 (residual GEMMs), 19: deferred epilogue (tools build)
 #ifdef VP_TOOLS
         static const int stagger_env = [] { const char* e = getenv("VP_G8_STAGGER"); return e ? atoi(e) : -1; }();
         if (stagger_env >= 0) {
             GemmArgs b = a;   // experiments: override the start stagger
             b.stagger = stagger_env;
-            return gemm8_launch(dtype, epi, b, a.variant == 17 ? 192 : 256, s);
+            return gemm8_launch(dtype, epi, b, a.variant == 17 ? 192 : 256, s, a.variant == 18 ? 192 : 256);
         }
 #endif
-        return gemm8_launch(dtype, epi, a, a.variant == 17 ? 192 : 256, s);
+        return gemm8_launch(dtype, epi, a, a.variant == 17 ? 192 : 256, s, a.variant == 18 ? 192 : 256);
     }
     if (a.persist) {   // persistent variant: wide 16-bit-output GEMMs on the default tile (a 256x256 instantiation spilled and was slower)
         if ((epi != EPI_BIAS && epi != EPI_BIAS_GELU) || a.variant != 8 || a.K % 128 || a.N % 8 || a.ldo != a.N || a.reverse ||

@@ -41,6 +41,10 @@
 //    from registers (a row's four lanes are one 64-column statistics granule).  Both replicate gemm.hip's summation tree:
 //    bit-identical statistics.
 //
+//  * 192(m) x 256(n) tiles (G8<256, 192>): X halves of 96 rows (12 DMA pieces: see gemm8_common.h for who issues which), three m-fragments
+//    per wave and half.  M of this model is always a multiple of 192 (a crop is 192 tokens) and N = 768 = 3 x 256: mlp.fc2 gets the
+//    register-direct residual epilogue and an operand ring that never stops (256 x 192 tiles drain and restart it for the LDS-staged one).
+//
 // Accumulation order per output element is the same as in gemm.hip (k ascending in steps of 32), so results are
 // bit-identical to the 2-phase kernels: that identity is the race screen (tools/gemm8_check.py, tests).
 #include <cstdio>
@@ -49,6 +53,9 @@
 #include "gemm8_common.h"
 #ifndef VP_G8_RESD
 #define VP_G8_RESD 1
+#endif
+#ifndef VP_G8_RESD192
+#define VP_G8_RESD192 1
 #endif
 
 
@@ -95,10 +102,10 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs g) {
     const char* xb = nullptr;   // current issue tile: X rows m0 + 8 w
     const char* wb = nullptr;   // W rows n0 (column permutation applied by wu0 / wu1 / voff_w)
     auto set_tile = [&](int m0, int n0) {
-        xb = g.a_blocked ? (const char*)(g.A + ((size_t)(m0 >> 6) * (K >> 6) << 12)) + (size_t)wave * 8 * 128
-                         : (const char*)(g.A + (size_t)(m0 + wave * 8) * K);
+        const int w8 = C::BM == 256 ? wave * 8 : 0;   // 192-row tiles form the row offset of every piece in issue()
+        xb = g.a_blocked ? (const char*)(g.A + ((size_t)(m0 >> 6) * (K >> 6) << 12)) + (size_t)w8 * 128
+                         : (const char*)(g.A + (size_t)(m0 + w8) * K);
         wb = (const char*)(g.W + (size_t)n0 * K);
-        (void)xrow_bytes;
     };
     // DMA of one slot of K-tile kt (of the issue tile) into ring buffer B
     auto issue = [&](int which, int B, int kt, bool force = false) {
@@ -109,9 +116,18 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs g) {
         uint32_t vx = voff_x, vw = voff_w;
         asm volatile("" : "+v"(vx), "+v"(vw));
         if (which < 2) {   // X half `which`
-            const char* src = xb + (size_t)(which * 2) * x64 + (size_t)kt * xkt + vx;
-            glds16(src, dst + which * C::HALF);
-            glds16(src + x64, dst + which * C::HALF + 8192);
+            if constexpr (C::BM == 256) {
+                const char* src = xb + (size_t)(which * 2) * x64 + (size_t)kt * xkt + vx;
+                glds16(src, dst + which * C::XH);
+                glds16(src + x64, dst + which * C::XH + 8192);
+            } else {   // 96 rows = pieces 0-11: wave w issues piece w; pieces 8-11 go to waves 0-3 (half 0: piece w + 8) / waves 4-7 (half 1: piece w + 4)
+                // tile row R (a multiple of 8: a piece never straddles a 64-row block) -> byte offset from the tile's first row (xb carries no wave term here)
+                auto xrow = [&](int R) { return g.a_blocked ? (size_t)(R >> 6) * x64 + (size_t)(R & 63) * 128 : (size_t)R * xrow_bytes; };
+                const char* src = xb + (size_t)kt * xkt + vx;
+                glds16(src + xrow(which * C::XR + wave * 8), dst + which * C::XH);
+                if (which == 0) { if (!wr) glds16(src + xrow(64 + wave * 8), dst + 8192); }
+                else { if (wr) glds16(src + xrow(C::XR + (wave + 4) * 8), dst + C::XH + 4096); }
+            }
         } else if (which == 2) {
             const char* src = wb + ((size_t)wu0 * K + (size_t)kt * 64) * 2 + vw;
             glds16(src, dst + C::OFF_W0);
@@ -126,19 +142,21 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs g) {
     // ---- fragment read offsets (bytes inside a slot) ----
     const int frow = lane & 15, fg = lane >> 4;
     const int foff = frow * 128 + ((fg ^ ((frow >> 1) & 7)) << 4);
-    const int xoff = wr * 64 * 128 + foff;            // X half h: + j * 2048, kk: ^ 64
+    const int xoff = wr * (C::XR / 2) * 128 + foff;   // X half h: + j * 2048, kk: ^ 64
     const int w0off = wc * 32 * 128 + foff;           // W half 0: + phi * 2048
     const int w1off = wc * 16 * C::NF1 * 128 + foff;  // W half 1
 
-    f32x4 acc[C::TI][8];
+    constexpr int MJ = C::MJ, TJ = C::TJ;             // m-fragments per X half / per wave
+    f32x4 acc[C::TI][TJ];
     // fragment registers: the current X half (both k-halves), W0, W1
-    u32x4 xs[4][2], fa[2][2], fb[2][2];
+    u32x4 xs[MJ][2], fa[2][2], fb[2][2];
+    auto rowJ = [](int J) { return (J / MJ) * C::XR + (J % MJ) * 16; };   // tile row of m-fragment J of a wave (+ wr XR/2 + lane row)
 
     auto zero_acc = [&]() {
 #pragma unroll
         for (int f = 0; f < C::TI; ++f)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) acc[f][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int j = 0; j < TJ; ++j) acc[f][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     };
 
 #ifndef VP_G8_ABL
@@ -158,7 +176,12 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs g) {
     // one K-tile t in ring buffer B (two segments, see the top of the file): kA / kB = K-tile indices (relative to the ISSUE tile
     // pointers) of the K-tiles whose X1 / X0, W0, W1 are restaged here; swB = switch the issue pointers to the next tile before LB's
     // restage.  MODE 1 = first K-tile of a tile (no wait in LA), 2 = last K-tile of a tile (deeper wait in LB).
-    constexpr int NKEEP = 6 + C::NW1;   // pieces of one LA (2) + one LB (4 + NW1) issue: what a counted wait leaves in flight
+    constexpr int NKEEP = C::NKEEP;   // pieces of one LA + one LB issue (BM = 256: 2 + 4 + NW1): what a counted wait leaves in flight
+    // the wait that leaves exactly one LB group in flight (last K-tile of a tile, ring start)
+    auto wait_lb = [&]() {
+        if constexpr (C::BM == 256) wait_vm<C::INFLIGHT>();
+        else { if (wr) wait_vm<3 + C::NW1>(); else wait_vm<4 + C::NW1>(); }
+    };
     auto ktile = [&](auto Bc, auto Mc, int kA, int kB, bool swB, int nm0, int nn0) {
         constexpr int B = decltype(Bc)::value;
         constexpr int MODE = decltype(Mc)::value;
@@ -174,7 +197,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs g) {
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) if (MODE == 1 || !(VP_G8_ABL & 1)) fb[p][kk] = *(const u32x4*)(sb + C::OFF_W1 + ((w1off + p * 2048) ^ (kk << 6)));
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < MJ; ++j)
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) if (MODE == 1 || !(VP_G8_ABL & 1)) xs[j][kk] = *(const u32x4*)(sb + C::OFF_X0 + ((xoff + j * 2048) ^ (kk << 6)));
         __builtin_amdgcn_sched_barrier(0);
@@ -192,11 +215,11 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs g) {
 #pragma unroll
             for (int p = 0; p < 2; ++p)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) if (!(VP_G8_ABL & 4)) acc[p][j] = mfma16<T>(fa[p][kk], xs[j][kk], acc[p][j]);
+                for (int j = 0; j < MJ; ++j) if (!(VP_G8_ABL & 4)) acc[p][j] = mfma16<T>(fa[p][kk], xs[j][kk], acc[p][j]);
 #pragma unroll
             for (int p = 0; p < C::NF1; ++p)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) if (!(VP_G8_ABL & 4)) acc[2 + p][j] = mfma16<T>(fb[p][kk], xs[j][kk], acc[2 + p][j]);
+                for (int j = 0; j < MJ; ++j) if (!(VP_G8_ABL & 4)) acc[2 + p][j] = mfma16<T>(fb[p][kk], xs[j][kk], acc[2 + p][j]);
         }
         __builtin_amdgcn_s_setprio(0);
         SEC(5);
@@ -204,7 +227,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs g) {
         SEC(6);
         // ---------------- LB: X1 | DMA X0, W0, W1 (t+2)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < MJ; ++j)
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) if (!(VP_G8_ABL & 1)) xs[j][kk] = *(const u32x4*)(sb + C::OFF_X1 + ((xoff + j * 2048) ^ (kk << 6)));
         __builtin_amdgcn_sched_barrier(0);
@@ -213,7 +236,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs g) {
         issue(0, B, kB);
         issue(3, B, kB);
         SEC(7);
-        if constexpr (MODE == 2) wait_vm<C::INFLIGHT>(); else wait_vm<NKEEP>();
+        if constexpr (MODE == 2) wait_lb(); else wait_vm<NKEEP>();
         wait_lgkm<0>();
         SEC(8);
         KBAR();
@@ -224,11 +247,11 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs g) {
 #pragma unroll
             for (int p = 0; p < 2; ++p)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) if (!(VP_G8_ABL & 4)) acc[p][4 + j] = mfma16<T>(fa[p][kk], xs[j][kk], acc[p][4 + j]);
+                for (int j = 0; j < MJ; ++j) if (!(VP_G8_ABL & 4)) acc[p][MJ + j] = mfma16<T>(fa[p][kk], xs[j][kk], acc[p][MJ + j]);
 #pragma unroll
             for (int p = 0; p < C::NF1; ++p)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) if (!(VP_G8_ABL & 4)) acc[2 + p][4 + j] = mfma16<T>(fb[p][kk], xs[j][kk], acc[2 + p][4 + j]);
+                for (int j = 0; j < MJ; ++j) if (!(VP_G8_ABL & 4)) acc[2 + p][MJ + j] = mfma16<T>(fb[p][kk], xs[j][kk], acc[2 + p][MJ + j]);
         }
         __builtin_amdgcn_s_setprio(0);
         SEC(10);
@@ -246,7 +269,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs g) {
     auto ring_start = [&]() {
         issue(2, 0, 0, true); issue(0, 0, 0, true); issue(3, 0, 0, true); issue(1, 0, 0, true);
         issue(2, 1, 1, true); issue(0, 1, 1, true); issue(3, 1, 1, true);   // X1 of K-tile 1 is issued by the first LA
-        wait_vm<C::INFLIGHT>();       // K-tile 0 landed; X0 / W0 / W1 of K-tile 1 stay in flight
+        wait_lb();                    // K-tile 0 landed; X0 / W0 / W1 of K-tile 1 stay in flight
         bar();
         if (wr) bar();   // stagger: waves 4-7 run one barrier behind waves 0-3
     };
@@ -310,7 +333,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs g) {
             // statistics and everything downstream stay bit-identical to the LDS-staged epilogues.  No LDS, no barrier: the operand
             // ring runs on across the tile boundary exactly as for the 16-bit epilogues.
             const int nb = n0 + wc * 64 + fg_e * 16;
-            const int mrow = m0 + wr * 64 + frow_e;
+            const int mrow = m0 + wr * (C::XR / 2) + frow_e;
             uint16_t* out_hi = (uint16_t*)g.out;
             uint16_t* out_lo = out_hi + g.plane;
             const uint16_t* aux_hi = (const uint16_t*)g.aux;
@@ -320,10 +343,10 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs g) {
             for (int f = 0; f < 4; ++f) bias4[f] = *(const f32x4*)(g.bias + nb + f * 4);
             const bool store = !(VP_ABLATE(g) & 8);
             const int gran = g.N >> 6;
-            constexpr int RD = VP_G8_RESD;   // residual of row group J: hi cols 0-7, hi 8-15, lo 0-7, lo 8-15; fetched RD row groups ahead
+            constexpr int RD = C::BM == 192 ? VP_G8_RESD192 : VP_G8_RESD;   // residual of row group J: hi cols 0-7, hi 8-15, lo 0-7, lo 8-15; fetched RD row groups ahead
             u32x4 res[RD + 1][4];
             auto load_res = [&](int J, u32x4(&r)[4]) {
-                const size_t o = (size_t)(mrow + (J >> 2) * 128 + (J & 3) * 16) * g.ldo + nb;
+                const size_t o = (size_t)(mrow + rowJ(J)) * g.ldo + nb;
                 r[0] = *(const u32x4*)(aux_hi + o);
                 r[1] = *(const u32x4*)(aux_hi + o + 8);
                 r[2] = *(const u32x4*)(aux_lo + o);
@@ -332,10 +355,10 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs g) {
 #pragma unroll
             for (int J = 0; J < RD; ++J) load_res(J, res[J]);
 #pragma unroll
-            for (int J = 0; J < 8; ++J) {
-                if (J + RD < 8) load_res(J + RD, res[(J + RD) % (RD + 1)]);
+            for (int J = 0; J < TJ; ++J) {
+                if (J + RD < TJ) load_res(J + RD, res[(J + RD) % (RD + 1)]);
                 const u32x4(&r)[4] = res[J % (RD + 1)];
-                const int m = mrow + (J >> 2) * 128 + (J & 3) * 16;
+                const int m = mrow + rowJ(J);
                 const size_t o = (size_t)m * g.ldo + nb;
                 float v[16];
 #pragma unroll
@@ -388,18 +411,18 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs g) {
             // variant is chosen by ONE wave-uniform branch around the whole block.
             const int nb = SPLIT ? n0 + wc * 64 + fg_e * 8 : n0 + wc * 16 * C::TI + fg_e * 4 * C::TI;
             auto fcol = [&](int f) { return SPLIT ? (f >> 1) * 32 + (f & 1) * 4 : f * 4; };   // first column of fragment f relative to nb
-            const int mrow = m0 + wr * 64 + frow_e;
+            const int mrow = m0 + wr * (C::XR / 2) + frow_e;
             auto epilogue = [&](auto LNc) {
                 constexpr bool LN = decltype(LNc)::value;
                 f32x4 bias4[C::TI], s4[LN ? C::TI : 1];
-                float2 st[LN ? 8 : 1];
+                float2 st[LN ? TJ : 1];
 #pragma unroll
                 for (int f = 0; f < C::TI; ++f) bias4[f] = *(const f32x4*)(g.bias + nb + fcol(f));
                 if constexpr (LN) {
 #pragma unroll
                     for (int f = 0; f < C::TI; ++f) s4[f] = *(const f32x4*)(g.ln_s + nb + fcol(f));
 #pragma unroll
-                    for (int J = 0; J < 8; ++J) st[J] = *(const float2*)(g.rowstat + 2 * (size_t)(mrow + (J >> 2) * 128 + (J & 3) * 16));
+                    for (int J = 0; J < TJ; ++J) st[J] = *(const float2*)(g.rowstat + 2 * (size_t)(mrow + rowJ(J)));
                 }
                 uint16_t* obase = g.out_blocked
                     ? (uint16_t*)g.out + (((size_t)(mrow >> 6) * (g.ldo >> 6) + (nb >> 6)) << 12) + ((mrow & 63) << 6) + (nb & 63)
@@ -407,10 +430,10 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs g) {
                 // + 16 rows: blocked 16 * 64 elements (mrow & 63 = wr-independent multiple: rows stay inside one 64-row block
                 // for (J & 3) 16 + frow_e < 64), + 128 rows: two block rows
                 const size_t step16 = g.out_blocked ? (size_t)16 * 64 : (size_t)16 * g.ldo;
-                const size_t step128 = g.out_blocked ? ((size_t)2 * (g.ldo >> 6) << 12) : (size_t)128 * g.ldo;
+                const size_t step128 = g.out_blocked ? ((size_t)2 * (g.ldo >> 6) << 12) : (size_t)C::XR * g.ldo;   // + one X half (blocked output: 256-row tiles only)
                 const bool store = !(VP_ABLATE(g) & 8);
 #pragma unroll
-                for (int J = 0; J < 8; ++J) {
+                for (int J = 0; J < TJ; ++J) {
                     uint32_t o[2 * C::TI];
 #pragma unroll
                     for (int f = 0; f < C::TI; ++f) {
@@ -428,7 +451,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs g) {
                         o[2 * f] = pack2<T>(v[0], v[1]);
                         o[2 * f + 1] = pack2<T>(v[2], v[3]);
                     }
-                    uint16_t* dst = obase + (size_t)(J >> 2) * step128 + (size_t)(J & 3) * step16;
+                    uint16_t* dst = obase + (size_t)(J / MJ) * step128 + (size_t)(J % MJ) * step16;
                     if (store) {
                         if constexpr (C::TI == 4) {
                             if (VP_ABLATE(g) & 64) {   // experiment: streaming (non-temporal) stores
@@ -465,6 +488,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs g) {
         } else {
             // Residual epilogue through LDS (the ring is drained first and restarted afterwards: fc2's 48 K-tiles make
             // the tile boundary cheap).  Arithmetic and statistics order = gemm.hip's fused-LayerNorm producer.
+            static_assert(C::BM == 256, "the LDS-staged residual epilogue is written for 256-row tiles");
             constexpr int ROWBYTES = C::BN * 4 + 16;
             constexpr int JPP = (C::BN == 256) ? 2 : 4;  // m-fragments (per wave and X half) staged per pass
             constexpr int CR = 32 * JPP;                 // rows per pass
@@ -601,24 +625,28 @@ static hipError_t launch8(const GemmArgs& a, hipStream_t s) {
 #endif
     grid &= ~7;
     if (grid < 8) return hipErrorInvalidValue;
-    if (a.desc) snprintf(a.desc, a.desc_cap, "gemm8_kernel<%s, %d, G8<%d>>", std::is_same<T, F16>::value ? "F16" : "BF16", EPI, C::BN);
+    if (a.desc) {
+        if (C::BM == 256) snprintf(a.desc, a.desc_cap, "gemm8_kernel<%s, %d, G8<%d>>", std::is_same<T, F16>::value ? "F16" : "BF16", EPI, C::BN);
+        else snprintf(a.desc, a.desc_cap, "gemm8_kernel<%s, %d, G8<%d, %d>>", std::is_same<T, F16>::value ? "F16" : "BF16", EPI, C::BN, C::BM);
+    }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(C::NT), LDS, s, a);
     return hipGetLastError();
 }
 
-bool gemm8_supported(int epi, const GemmArgs& a, int bn) {
+bool gemm8_supported(int epi, const GemmArgs& a, int bn, int bm) {
     if (epi != EPI_BIAS && epi != EPI_BIAS_GELU && epi != EPI_BIAS_RESID_LN) return false;
     if (bn != 256 && bn != 192) return false;
-    if (a.M % 256 || a.N % bn || a.K % 128 || a.K < 256) return false;
+    if (bm != 256 && !(bm == 192 && bn == 256 && epi == EPI_BIAS_RESID_LN)) return false;   // 192-row tiles: the residual GEMMs
+    if (a.M % bm || a.N % bn || a.K % 128 || a.K < 256) return false;
     if ((size_t)a.M * a.K * 2 >= (1ull << 32) || (size_t)a.w_rows * a.K * 2 >= (1ull << 32)) return false;   // 32-bit per-lane offsets
-    if ((a.M / 256) * (a.N / bn) < 8) return false;
+    if ((a.M / bm) * (a.N / bn) < 8) return false;
     if (epi == EPI_BIAS_RESID_LN) return a.ldo == a.N && a.plane && a.stats_out && !a.out_blocked;
     if ((size_t)a.M * a.N >= (1ull << 31)) return false;
     return bn == 256 && a.ldo == a.N;   // wide 16-bit-output GEMMs: 256 x 256 tiles only
 }
 
-hipError_t gemm8_launch(int dtype, int epi, const GemmArgs& a, int bn, hipStream_t s) {
-    if (!gemm8_supported(epi, a, bn)) return hipErrorInvalidValue;
+hipError_t gemm8_launch(int dtype, int epi, const GemmArgs& a, int bn, hipStream_t s, int bm) {
+    if (!gemm8_supported(epi, a, bn, bm)) return hipErrorInvalidValue;
 #ifdef VP_TOOLS
     if (a.variant == 19) return gemm8_deferred_launch(dtype, epi, a, s);   // experimental variant, own translation unit (measured, not shipped)
 #else
@@ -628,6 +656,7 @@ hipError_t gemm8_launch(int dtype, int epi, const GemmArgs& a, int bn, hipStream
     do {                                                                                                                \
         if (epi == EPI_BIAS) return launch8<TY, EPI_BIAS, G8<256>>(a, s);                                               \
         if (epi == EPI_BIAS_GELU) return launch8<TY, EPI_BIAS_GELU, G8<256>>(a, s);                                     \
+        if (bm == 192) return launch8<TY, EPI_BIAS_RESID_LN, G8<256, 192>>(a, s);                                       \
         if (bn == 256) return launch8<TY, EPI_BIAS_RESID_LN, G8<256>>(a, s);                                            \
         return launch8<TY, EPI_BIAS_RESID_LN, G8<192>>(a, s);                                                           \
     } while (0)

@@ -9,18 +9,26 @@
 namespace vp {
 namespace {
 
-template <int BN_> struct G8 {
-    static constexpr int BM = 256, BN = BN_, NT = 512;
+template <int BN_, int BM_ = 256> struct G8 {
+    static constexpr int BM = BM_, BN = BN_, NT = 512;
+    static constexpr int XR = BM / 2;               // rows of an X half (128; 96 for the 192-row tile)
+    static constexpr int MJ = XR / 32;              // m-fragments of a wave per X half (4 or 3)
     static constexpr int WH1 = BN - 128;            // rows of W half 1 (128 or 64)
     static constexpr int NF1 = WH1 / 64;            // n-fragments of a wave from W half 1 (2 or 1)
-    static constexpr int TI = 2 + NF1, TJ = 8;      // fragments per wave: n, m
+    static constexpr int TI = 2 + NF1, TJ = 2 * MJ; // fragments per wave: n, m
     static constexpr int HALF = 128 * 128;          // bytes of a 128-row slot (BK = 64 16-bit values per row)
-    static constexpr int OFF_X0 = 0, OFF_X1 = HALF, OFF_W0 = 2 * HALF, OFF_W1 = 3 * HALF;
-    static constexpr int BUF = 3 * HALF + WH1 * 128;
+    static constexpr int XH = XR * 128;             // bytes of an X slot
+    static constexpr int OFF_X0 = 0, OFF_X1 = XH, OFF_W0 = 2 * XH, OFF_W1 = 2 * XH + HALF;
+    static constexpr int BUF = 2 * XH + HALF + WH1 * 128;
     static constexpr int RING = 2 * BUF;
     static constexpr int NW1 = WH1 / 64;            // DMA instructions per wave for W half 1
-    static constexpr int INFLIGHT = 4 + NW1;        // DMAs of the three youngest slots (W0, X0, W1) at the counted wait
+    static constexpr int INFLIGHT = 4 + NW1;        // BM = 256: DMAs of the three youngest slots (W0, X0, W1) at the counted wait
+    // BM = 192: an X half is 12 DMA pieces for 8 waves.  Waves 0-3 issue two pieces of X0 and one of X1, waves 4-7 one of X0 and two of
+    // X1: every wave issues 5 + NW1 pieces per K-tile, the steady-state counted wait (NKEEP) is the same for all of them, and only the
+    // two waits that leave exactly one LB group in flight (tile boundary, ring start) differ by wave group.
+    static constexpr int NKEEP = (BM == 256 ? 6 : 5) + NW1;
     static_assert(BN == 256 || BN == 192, "BN");
+    static_assert(BM == 256 || (BM == 192 && BN == 256), "BM");
 };
 
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }

@@ -97,8 +97,8 @@ struct GemmArgs {
 hipError_t gemm_launch(int dtype, int epi, const GemmArgs& a, hipStream_t s);
 // 8-phase persistent kernel (gemm8.hip): 256 x bn tiles (bn = 256 or 192), EPI_BIAS / EPI_BIAS_GELU / EPI_BIAS_RESID_LN.
 // Selected through GemmArgs::variant 16 (bn 256) / 17 (bn 192) in gemm_launch.
-bool gemm8_supported(int epi, const GemmArgs& a, int bn);
-hipError_t gemm8_launch(int dtype, int epi, const GemmArgs& a, int bn, hipStream_t s);
+bool gemm8_supported(int epi, const GemmArgs& a, int bn, int bm = 256);
+hipError_t gemm8_launch(int dtype, int epi, const GemmArgs& a, int bn, hipStream_t s, int bm = 256);
 #ifdef VP_TOOLS
 hipError_t gemm8_deferred_launch(int dtype, int epi, const GemmArgs& a, hipStream_t s);   // gemm8d.hip, variant 19 (measured, not shipped)
 #endif

@@ -17,12 +17,16 @@ import pytest
 SLOTS = ('X0', 'X1', 'W0', 'W1')
 
 
-def program(group, ntiles, nk, bn, epi, mut=None):
+def program(group, ntiles, nk, bn, epi, mut=None, bm=256):
     """Event list of one wave group (0 = waves 0-3, 1 = waves 4-7).  Events: ('issue', slot, buf, tile, kt, pieces), ('wait', n), ('bar',),
     ('read', slot, buf, tile, kt), ('vm', n) = n other vector-memory operations (epilogue stores) entering the same in-order counter."""
     nw1 = 2 if bn == 256 else 1                       # gemm8_common.h G8<BN>: W1 is 128 (2 pieces per wave) or 64 rows (1 piece)
     pieces = {'X0': 2, 'X1': 2, 'W0': 2, 'W1': nw1}   # gemm8.hip issue(): glds16 calls per wave and slot
     nkeep, inflight = 6 + nw1, 4 + nw1                # gemm8.hip: NKEEP, G8::INFLIGHT
+    if bm == 192:                                     # G8<256, 192>: an X half is 12 pieces -- waves 0-3 issue 2 of X0 and 1 of X1, waves 4-7 the reverse
+        pieces['X0'], pieces['X1'] = (2, 1) if group == 0 else (1, 2)
+        nkeep = 5 + nw1                               # the same for both groups (gemm8_common.h NKEEP)
+        inflight = (4 if group == 0 else 3) + nw1     # gemm8.hip wait_lb(): one LB group of THIS wave group
     if mut == 'nkeep+1':
         nkeep += 1
     if mut == 'inflight+1':
@@ -95,8 +99,8 @@ def program(group, ntiles, nk, bn, epi, mut=None):
     return ev
 
 
-def check(ntiles, nk, bn, epi, mut=None):
-    progs = [program(g, ntiles, nk, bn, epi, mut) for g in (0, 1)]
+def check(ntiles, nk, bn, epi, mut=None, bm=256):
+    progs = [program(g, ntiles, nk, bn, epi, mut, bm) for g in (0, 1)]
     segs = []
     for p in progs:                                   # segment k of a group runs between global barriers k and k + 1
         s, cur = [], []
@@ -159,6 +163,19 @@ def check(ntiles, nk, bn, epi, mut=None):
 def test_operand_ring_has_no_hazard(ntiles, nk, bn, epi):
     errors = check(ntiles, nk, bn, epi)
     assert not errors, errors[:5]
+
+
+@pytest.mark.parametrize('ntiles,nk', list(itertools.product((1, 2, 3, 9), (4, 6, 12, 16, 48))))
+def test_operand_ring_of_the_192_row_tile_has_no_hazard(ntiles, nk):
+    """192 x 256 tiles: the two wave groups issue different piece counts per section (X halves of 12 pieces) -- the steady-state count is common, the
+    one-LB-group waits are per group"""
+    errors = check(ntiles, nk, 256, 'resid_reg', bm=192)
+    assert not errors, errors[:5]
+
+
+@pytest.mark.parametrize('mut', ['nkeep+1', 'inflight+1'])
+def test_the_checker_bites_on_the_192_row_tile(mut):
+    assert check(3, 12, 256, 'resid_reg', mut, bm=192), f'mutation {mut} went unnoticed'
 
 
 @pytest.mark.parametrize('mut', ['nkeep+1', 'inflight+1', 'early_x1'])

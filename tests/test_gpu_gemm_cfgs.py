@@ -92,7 +92,7 @@ def test_residual_gemm_configurations(operands, name, K, flags):
     x0 = hi.astype(np.float64) + round_to(resid - hi, 'fp16').astype(np.float64)          # what the two planes hold
     ref = A.astype(np.float64) @ W.astype(np.float64).T + bias + x0
     outs = {}
-    for label, variant in [('cfg11', 11), ('cfg8', 8), ('cfg9', 9), ('gemm8 256x192', 17), ('gemm8 256x256', 16)]:
+    for label, variant in [('cfg11', 11), ('cfg8', 8), ('cfg9', 9), ('gemm8 256x192', 17), ('gemm8 256x256', 16), ('gemm8 192x256', 18)]:
         o, st = _case(6, variant, flags, A, W, bias, aux=resid, want_stats=True, group_m=0 if variant < 16 else 8)
         outs[label] = (o, st)
         assert np.abs(o - ref).max() < 2e-5 * max(1.0, np.abs(ref).max()), f'{name} {label}: planes off by {np.abs(o - ref).max():.3e}'
@@ -103,6 +103,30 @@ def test_residual_gemm_configurations(operands, name, K, flags):
     bo, bs = outs['cfg11']
     for label, (o, st) in outs.items():
         assert np.array_equal(o, bo) and np.array_equal(st, bs), f'{name}: {label} differs from cfg11'
+
+
+@pytest.mark.parametrize('K,rows', [(768, 192 * 136), (3072, 192 * 136), (768, 192 * 7)])
+def test_residual_gemm_192_row_tiles_across_tile_boundaries(K, rows):
+    """The 8-phase kernel's 192 x 256 tile (X halves of 96 rows: uneven DMA piece counts per wave group, register-direct residual
+    epilogue, the ring running on across tile boundaries) at a row count where workgroups own ONE OR TWO tiles (136 x 3 = 408 tiles on 256
+    workgroups) and at a row count only this tile shape divides (1344 rows = 7 crops: not a multiple of 256): planes and statistics bit for
+    bit those of the 2-phase kernel."""
+    rng = np.random.default_rng(K + rows)
+    A = round_to((rng.standard_normal((rows, K)) * (1.0 if K == D else 0.5)).astype(np.float32), 'fp16')
+    W = round_to((rng.standard_normal((D, K)) * 0.03).astype(np.float32), 'fp16')
+    bias = (rng.standard_normal(D) * 0.1).astype(np.float32)
+    resid = (rng.standard_normal((rows, D)) * 2.0).astype(np.float32)
+    flags = 0 if K == D else AB | REV                     # fc2 reads its activations in the 64 x 64-blocked layout fc1 writes
+    o11, s11 = _case(6, 11, flags, A, W, bias, aux=resid, want_stats=True, group_m=0)
+    for gm in (2, 8):
+        o18, s18 = _case(6, 18, flags, A, W, bias, aux=resid, want_stats=True, group_m=gm)
+        assert np.array_equal(o18, o11) and np.array_equal(s18, s11), f'192 x 256 tiles (group_m {gm}) differ from cfg11 in {(o18 != o11).sum()} elements'
+    # (and the values themselves, on a sample of rows: the bit identity above carries it to all of them)
+    idx = rng.choice(rows, 64, replace=False)
+    hi = round_to(resid[idx], 'fp16')
+    x0 = hi.astype(np.float64) + round_to(resid[idx] - hi, 'fp16').astype(np.float64)
+    ref = A[idx].astype(np.float64) @ W.astype(np.float64).T + bias + x0
+    assert np.abs(o11[idx] - ref).max() < 2e-5 * max(1.0, np.abs(ref).max())
 
 
 def test_patch_embed_epilogue_with_statistics(operands):

@@ -158,7 +158,7 @@ def test_residual_gemm_configurations_large_models(name, N, K, flags):
     x0 = hi.astype(np.float64) + round_to(resid - hi, 'fp16').astype(np.float64)
     ref = (torch.from_numpy(A).double() @ torch.from_numpy(W).double().T).numpy() + bias + x0
     outs = {}
-    for label, variant in [('cfg11', 11), ('cfg9', 9), ('gemm8 256x256 register epilogue', 16)]:
+    for label, variant in [('cfg11', 11), ('cfg9', 9), ('gemm8 256x256 register epilogue', 16), ('gemm8 192x256 register epilogue', 18)]:
         o, st = _case(6, variant, flags, A, W, bias, aux=resid, want_stats=True, group_m=0 if variant < 16 else 2)
         assert np.abs(o - ref).max() < 2e-5 * max(1.0, np.abs(ref).max()), f'{name} {label}: planes off by {np.abs(o - ref).max():.3e}'
         g = o.astype(np.float64).reshape(M, N // 64, 64)
