@@ -452,6 +452,12 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs g) {
                         o[2 * f + 1] = pack2<T>(v[2], v[3]);
                     }
                     uint16_t* dst = obase + (size_t)(J / MJ) * step128 + (size_t)(J % MJ) * step16;
+                    if constexpr (C::BM != 256) {   // 192-row tiles: a wave's 48 rows of an X half straddle 64-row blocks -- blocked output addressed row by row
+                        if (g.out_blocked) {
+                            const int row = mrow + rowJ(J);
+                            dst = (uint16_t*)g.out + (((size_t)(row >> 6) * (g.ldo >> 6) + (nb >> 6)) << 12) + ((row & 63) << 6) + (nb & 63);
+                        }
+                    }
                     if (store) {
                         if constexpr (C::TI == 4) {
                             if (VP_ABLATE(g) & 64) {   // experiment: streaming (non-temporal) stores
@@ -636,7 +642,7 @@ static hipError_t launch8(const GemmArgs& a, hipStream_t s) {
 bool gemm8_supported(int epi, const GemmArgs& a, int bn, int bm) {
     if (epi != EPI_BIAS && epi != EPI_BIAS_GELU && epi != EPI_BIAS_RESID_LN) return false;
     if (bn != 256 && bn != 192) return false;
-    if (bm != 256 && !(bm == 192 && bn == 256 && epi == EPI_BIAS_RESID_LN)) return false;   // 192-row tiles: the residual GEMMs
+    if (bm != 256 && !(bm == 192 && bn == 256)) return false;   // 192-row tiles: 256 columns wide
     if (a.M % bm || a.N % bn || a.K % 128 || a.K < 256) return false;
     if ((size_t)a.M * a.K * 2 >= (1ull << 32) || (size_t)a.w_rows * a.K * 2 >= (1ull << 32)) return false;   // 32-bit per-lane offsets
     if ((a.M / bm) * (a.N / bn) < 8) return false;
@@ -654,8 +660,8 @@ hipError_t gemm8_launch(int dtype, int epi, const GemmArgs& a, int bn, hipStream
 #endif
 #define VP_G8(TY)                                                                                                       \
     do {                                                                                                                \
-        if (epi == EPI_BIAS) return launch8<TY, EPI_BIAS, G8<256>>(a, s);                                               \
-        if (epi == EPI_BIAS_GELU) return launch8<TY, EPI_BIAS_GELU, G8<256>>(a, s);                                     \
+        if (epi == EPI_BIAS) return bm == 192 ? launch8<TY, EPI_BIAS, G8<256, 192>>(a, s) : launch8<TY, EPI_BIAS, G8<256>>(a, s);                \
+        if (epi == EPI_BIAS_GELU) return bm == 192 ? launch8<TY, EPI_BIAS_GELU, G8<256, 192>>(a, s) : launch8<TY, EPI_BIAS_GELU, G8<256>>(a, s);  \
         if (bm == 192) return launch8<TY, EPI_BIAS_RESID_LN, G8<256, 192>>(a, s);                                       \
         if (bn == 256) return launch8<TY, EPI_BIAS_RESID_LN, G8<256>>(a, s);                                            \
         return launch8<TY, EPI_BIAS_RESID_LN, G8<192>>(a, s);                                                           \

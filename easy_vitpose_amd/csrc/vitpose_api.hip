@@ -100,7 +100,7 @@ struct vp_ctx {
     bool blocked_qkv = true;          // qkv in the same blocked layout when the head dim is 64 (a (crop, head) slab = three contiguous 8 KiB blocks; VP_BLOCKED_QKV=0: row-major)
     bool fuse_ln = true;              // LayerNorm folded into the GEMMs on both sides of it (VP_FUSE_LN=0: standalone passes)
     bool fuse_qkv_attn = true;        // head dim 64, even batches of >= 128 (pair, head) tiles: attn.qkv + attention core in one kernel (VP_FUSE_QKV_ATTN=0: two launches)
-    bool g8_bm192 = true;             // the 8-phase kernel's 192 x 256 tile (residual GEMMs) is a candidate
+    int g8_bm192 = 3;                 // the 8-phase kernel's 192 x 256 tile is a candidate for: 1 = the residual GEMMs, 2 = the wide GEMMs
     bool deconv_parity_fast = true;   // head: the four output parities of a deconv tile run side by side on one XCD (VP_DECONV_PARITY_FAST=0: parity-major launch order)
     float *ln_part = nullptr, *rowstat = nullptr;   // partial row statistics [M][D/64][2], (mean, rstd) [M][2]
     // fp8 mode (vp_config.dtype = VP_DTYPE_FP8; csrc/mx8.h, gemm8f.hip, quant8.hip): qkv / fc1 / fc2 on MXFP8 operands.  Token rows are
@@ -462,7 +462,7 @@ int gemm(vp_ctx* c, int fam, int epi, const uint16_t* A, const uint16_t* W, cons
         // tile shape: the 256-row candidate (256 x 256; for the residual GEMMs also 256 x 192) whose tile count fills the rounds of 256
         // persistent workgroups best.  The kernel is used from 1.75 tiles per CU, or for a smaller launch when its last round is >= 80 % full
         // (measured at batch 32 - 128: ViTPose-B qkv at 216 / 432 tiles -15 % / -5 %, fc2 at 216 tiles -23 %, but fc1 / fc2 at
-        // 288 tiles = 56 % full +20 %; ViTPose-H fc2 at batch 128, 480 tiles: 329 -> 279 us).  Residual GEMMs no 256-row tile qualifies for
+        // 288 tiles = 56 % full +20 %; ViTPose-H fc2 at batch 128, 480 tiles: 329 -> 279 us).  GEMMs no 256-row tile qualifies for
         // (row count not a multiple of 256, or a badly filled last round) get a second chance on 192 x 256 tiles -- M is always a multiple
         // of 192: ViTPose-L fc2 at 64 crops, 192 tiles of 256 x 256 = 75 % full -> 256 tiles of 192 x 256: +2.9 % end to end.  At equal fill the
         // 256 x 192 tile is faster (ViTPose-B fc2 at 256 crops: 768 tiles either way, 192 x 256 +5 % slower: profiles/gemm8_bm192_r4.txt).
@@ -479,10 +479,13 @@ int gemm(vp_ctx* c, int fam, int epi, const uint16_t* A, const uint16_t* W, cons
         auto qualifies = [&](long t, double f) { return t >= min_tiles || (f >= 0.8 && t >= 192); };
         for (int i = 0; i < 3; ++i) {
             const Cand& cd = cands[i];
-            if (M % cd.bm || N % cd.bn || (wide && cd.variant != 16)) continue;
-            if (cd.variant == 18 && (!c->g8_bm192 || (pick >= 0 && qualifies(tiles, fill)))) continue;   // only when no 256-row tile qualifies
+            if (M % cd.bm || N % cd.bn || (wide && cd.variant == 17)) continue;
+            if (cd.variant == 18 && (!(c->g8_bm192 & (wide ? 2 : 1)) || (pick >= 0 && qualifies(tiles, fill)))) continue;   // only when no 256-row tile qualifies
             const long t = (long)(M / cd.bm) * (N / cd.bn);
-            const double f = (double)t / (double)((t + 255) / 256 * 256);
+            // the launch is min(t, 256) workgroups ROUNDED DOWN to a multiple of 8 (one contiguous tile range per XCD): 252 tiles are 248 workgroups
+            // and two rounds (measured: ViTPose-L fc2 at 63 crops 108 -> 147 us), not 98 % of one
+            const long wgs = std::max<long>((t < 256 ? t : 256) & ~7L, 8);
+            const double f = (double)t / (double)((t + wgs - 1) / wgs * 256);   // share of 256 CUs x rounds that computes a tile
             if (f > fill + 1e-9 || (cd.variant == 18 && qualifies(t, f))) { pick = i; tiles = t; fill = f; }
         }
         if (pick >= 0 && qualifies(tiles, fill) && vp::gemm8_supported(epi, g, cands[pick].bn, cands[pick].bm)) {
@@ -826,7 +829,7 @@ int vp_create(vp_handle* out, const vp_config* cfg) {
     if (const char* f = getenv("VP_BLOCKED_QKV")) c->blocked_qkv = atoi(f) != 0;
     if (const char* f = getenv("VP_FUSE_QKV_ATTN")) c->fuse_qkv_attn = atoi(f) != 0;
     if (const char* f = getenv("VP_DECONV_PARITY_FAST")) c->deconv_parity_fast = atoi(f) != 0;
-    if (const char* f = getenv("VP_G8_BM192")) c->g8_bm192 = atoi(f) != 0;   // 0: the residual GEMMs never take the 192 x 256 tile of the 8-phase kernel
+    if (const char* f = getenv("VP_G8_BM192")) c->g8_bm192 = atoi(f);   // mask: 1 = residual GEMMs, 2 = wide GEMMs may take the 192 x 256 tile of the 8-phase kernel (0: never)
     if (const char* f = getenv("VP_GEMM8")) c->gemm8_mask = atoi(f);   // which GEMMs may take the 8-phase kernel (1 fc2, 2 fc1, 4 qkv, 8 proj; 0 = the 2-phase kernels everywhere)
 #ifdef VP_TOOLS   // development switches of the measurement build (tools/)
     if (const char* f = getenv("VP_BLOCKED_HID")) c->blocked_hid = atoi(f) != 0;

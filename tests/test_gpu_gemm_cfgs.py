@@ -65,7 +65,7 @@ def test_wide_gemm_configurations(operands, name, N, epi, flags):
         ref = _gelu(ref)
     outs = {}
     for label, variant, fl in [('cfg9', 9, 0), ('cfg1', 1, 0), ('cfg8', 8, 0), ('cfg8 persistent', 8, PERS), ('cfg11', 11, 0),
-                               ('gemm8 256x256', 16, 0), ('cfg8 reversed', 8, REV)]:
+                               ('gemm8 256x256', 16, 0), ('gemm8 192x256', 18, 0), ('cfg8 reversed', 8, REV)]:
         outs[label] = _case(epi, variant, flags | fl, A, W, bias, rowstat=rowstat, ln_s=ln_s)
         _check16(outs[label], ref, f'{name} {label}')
     base = outs['cfg9']
@@ -75,8 +75,15 @@ def test_wide_gemm_configurations(operands, name, N, epi, flags):
     plain = A.astype(np.float64) @ W.astype(np.float64).T + bias
     if epi == 1:
         plain = _gelu(plain)
-    for label, variant, fl in [('cfg8 persistent', 8, PERS), ('gemm8', 16, 0)]:
+    for label, variant, fl in [('cfg8 persistent', 8, PERS), ('gemm8', 16, 0), ('gemm8 192x256', 18, 0)]:
         _check16(_case(epi, variant, flags | fl, A, W, bias), plain, f'{name} {label} (no fold)')
+    # a row count only the 192-row tile divides (25 crops = 4800 rows: 25 x 9 / 25 x 12 tiles, workgroups with one and with two tiles; blocked output
+    # rows that straddle 64-row blocks): bit for bit the 2-phase kernel
+    r = 192 * 25
+    a = _case(epi, 18, flags, A[:r], W, bias, rowstat=rowstat[:r], ln_s=ln_s)
+    b = _case(epi, 9, flags, A[:r], W, bias, rowstat=rowstat[:r], ln_s=ln_s)
+    assert np.array_equal(a, b), f'{name}: 192 x 256 tiles at {r} rows differ from cfg9 in {(a != b).sum()} elements'
+    assert np.array_equal(a, base[:r])
 
 
 @pytest.mark.parametrize('name,K,flags', [('proj', D, 0), ('fc2', 4 * D, AB | REV)])
