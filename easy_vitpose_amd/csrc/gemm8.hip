@@ -629,7 +629,7 @@ static hipError_t launch8(const GemmArgs& a, hipStream_t s) {
     static const int max_wgs = [] { const char* e = getenv("VP_G8_WGS"); return e ? atoi(e) : 256; }();
     if (grid > max_wgs) grid = max_wgs;
 #endif
-    grid &= ~7;
+    if (grid >= 256) grid &= ~7;   // (only the tools override can make it a smaller non-multiple; below 256 tiles: one workgroup per tile)
     if (grid < 8) return hipErrorInvalidValue;
     if (a.desc) {
         if (C::BM == 256) snprintf(a.desc, a.desc_cap, "gemm8_kernel<%s, %d, G8<%d>>", std::is_same<T, F16>::value ? "F16" : "BF16", EPI, C::BN);

@@ -56,7 +56,10 @@ struct TileWalk {   // XCD-contiguous, grouped tile order (same as gemm.hip's pe
         const int ntiles = tiles_m * tiles_n;
         const int xcd = blockIdx.x & 7;
         j0 = blockIdx.x >> 3;
-        nloc = gridDim.x >> 3;
+        // workgroups on this XCD.  A launch of fewer than 256 tiles is one workgroup per tile, whatever the count: XCD x then holds
+        // (G >> 3) + (x < (G & 7)) workgroups and owns exactly as many tiles -- nobody has a second tile.  (Rounding the grid down to a multiple
+        // of 8 sent the last 1-7 tiles of e.g. a 252-tile launch into a second round: ViTPose-L fc2 at 63 crops 108 -> 147 us.)
+        nloc = (gridDim.x >> 3) + (xcd < (int)(gridDim.x & 7) ? 1 : 0);
         const int q = ntiles >> 3, r8 = ntiles & 7;
         base = (xcd < r8) ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q;
         cnt = q + (xcd < r8 ? 1 : 0);

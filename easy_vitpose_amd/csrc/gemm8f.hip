@@ -491,8 +491,7 @@ static hipError_t launch8f(const GemmArgs& a, hipStream_t s) {
         if (dev >= 0 && dev < 64) attr_done[dev] = true;
     }
     const int tiles = (a.M / C::BM) * (a.N / C::BN);
-    int grid = tiles < 256 ? tiles : 256;
-    grid &= ~7;
+    const int grid = tiles < 256 ? tiles : 256;   // below 256 tiles: one workgroup per tile (TileWalk handles any count)
     if (grid < 8) return hipErrorInvalidValue;
     if (a.desc) snprintf(a.desc, a.desc_cap, "gemm8f_kernel<%d, G8<%d>>", EPI, C::BN);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(C::NT), LDS, s, a);

@@ -56,7 +56,8 @@ __global__ __launch_bounds__(512, 2) void qkvattn_kernel(QkvAttnArgs g) {
     // tile walk: XCD x (= blockIdx & 7) owns a contiguous range of (pair, head) tiles, head fastest: the workgroups resident on one XCD
     // share a few X panels and the whole weight matrix in its L2
     const int ntiles = g.npairs * g.heads;
-    const int xcd = blockIdx.x & 7, j0 = blockIdx.x >> 3, nloc = gridDim.x >> 3;
+    const int xcd = blockIdx.x & 7, j0 = blockIdx.x >> 3;
+    const int nloc = (gridDim.x >> 3) + (xcd < (int)(gridDim.x & 7) ? 1 : 0);   // workgroups on this XCD (fewer than 256 tiles: one workgroup per tile, any count)
     const int tq = ntiles >> 3, tr8 = ntiles & 7;
     const int tbase = (xcd < tr8) ? xcd * (tq + 1) : tr8 * (tq + 1) + (xcd - tr8) * tq;
     const int tcnt = tq + (xcd < tr8 ? 1 : 0);
@@ -415,8 +416,7 @@ bool qkvattn_supported(const QkvAttnArgs& a) {
 hipError_t qkvattn_launch(int dtype, const QkvAttnArgs& a, hipStream_t s, char* desc, int desc_cap) {
     if (!qkvattn_supported(a)) return hipErrorInvalidValue;
     const int tiles = a.npairs * a.heads;
-    int grid = tiles < 256 ? tiles : 256;
-    grid &= ~7;
+    const int grid = tiles < 256 ? tiles : 256;
     static bool attr_done[2][64] = {};
     int dev = 0;
     (void)hipGetDevice(&dev);

@@ -482,10 +482,7 @@ int gemm(vp_ctx* c, int fam, int epi, const uint16_t* A, const uint16_t* W, cons
             if (M % cd.bm || N % cd.bn || (wide && cd.variant == 17)) continue;
             if (cd.variant == 18 && (!(c->g8_bm192 & (wide ? 2 : 1)) || (pick >= 0 && qualifies(tiles, fill)))) continue;   // only when no 256-row tile qualifies
             const long t = (long)(M / cd.bm) * (N / cd.bn);
-            // the launch is min(t, 256) workgroups ROUNDED DOWN to a multiple of 8 (one contiguous tile range per XCD): 252 tiles are 248 workgroups
-            // and two rounds (measured: ViTPose-L fc2 at 63 crops 108 -> 147 us), not 98 % of one
-            const long wgs = std::max<long>((t < 256 ? t : 256) & ~7L, 8);
-            const double f = (double)t / (double)((t + wgs - 1) / wgs * 256);   // share of 256 CUs x rounds that computes a tile
+            const double f = (double)t / (double)((t + 255) / 256 * 256);   // share of 256 CUs x rounds that computes a tile (below 256 tiles: one workgroup per tile)
             if (f > fill + 1e-9 || (cd.variant == 18 && qualifies(t, f))) { pick = i; tiles = t; fill = f; }
         }
         if (pick >= 0 && qualifies(tiles, fill) && vp::gemm8_supported(epi, g, cands[pick].bn, cands[pick].bm)) {
