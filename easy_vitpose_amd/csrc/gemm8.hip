@@ -631,10 +631,8 @@ static hipError_t launch8(const GemmArgs& a, hipStream_t s) {
 #endif
     if (grid >= 256) grid &= ~7;   // (only the tools override can make it a smaller non-multiple; below 256 tiles: one workgroup per tile)
     if (grid < 8) return hipErrorInvalidValue;
-    if (a.desc) {
-        if (C::BM == 256) snprintf(a.desc, a.desc_cap, "gemm8_kernel<%s, %d, G8<%d>>", std::is_same<T, F16>::value ? "F16" : "BF16", EPI, C::BN);
-        else snprintf(a.desc, a.desc_cap, "gemm8_kernel<%s, %d, G8<%d, %d>>", std::is_same<T, F16>::value ? "F16" : "BF16", EPI, C::BN, C::BM);
-    }
+    // (the name rocprofv3 prints for this instantiation: G8<BN, BM>)
+    if (a.desc) snprintf(a.desc, a.desc_cap, "gemm8_kernel<%s, %d, G8<%d, %d>>", std::is_same<T, F16>::value ? "F16" : "BF16", EPI, C::BN, C::BM);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(C::NT), LDS, s, a);
     return hipGetLastError();
 }

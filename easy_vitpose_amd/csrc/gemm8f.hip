@@ -493,7 +493,7 @@ static hipError_t launch8f(const GemmArgs& a, hipStream_t s) {
     const int tiles = (a.M / C::BM) * (a.N / C::BN);
     const int grid = tiles < 256 ? tiles : 256;   // below 256 tiles: one workgroup per tile (TileWalk handles any count)
     if (grid < 8) return hipErrorInvalidValue;
-    if (a.desc) snprintf(a.desc, a.desc_cap, "gemm8f_kernel<%d, G8<%d>>", EPI, C::BN);
+    if (a.desc) snprintf(a.desc, a.desc_cap, "gemm8f_kernel<%d, G8<%d, %d>>", EPI, C::BN, C::BM);   // as rocprofv3 prints it
     hipLaunchKernelGGL(kern, dim3(grid), dim3(C::NT), LDS, s, a);
     return hipGetLastError();
 }
