@@ -220,6 +220,52 @@ def test_fused_qkv_attention_is_bit_identical(monkeypatch, variant, dataset, dty
     assert np.array_equal(odd, ref_kp[:n - 1])
 
 
+@pytest.mark.parametrize('variant,dataset,n', [('b', 'coco', 85), ('l', 'coco_25', 63), ('b', 'coco', 26)])
+def test_192_row_tiles_and_odd_tile_counts_are_bit_identical(monkeypatch, variant, dataset, n):
+    """Batches whose row count no 256-row tile divides (three of four batch sizes): fc1 / fc2 on the 8-phase kernel's 192 x 256 tile (VP_G8_BM192, a
+    product-side switch) and launches of a tile count that is no multiple of 8 (one workgroup per tile: 255 / 252 fc2 tiles, 156 fused
+    qkv + attention tiles at 26 crops) against the 2-phase kernels: keypoints and backbone tokens bit for bit, three runs."""
+    shp, sd, _ = weights(variant, dataset)
+    crops = synthetic_crops(n, 61, 'blobs')
+    crops[n // 2:] = synthetic_crops(n - n // 2, 62, 'noise')
+    monkeypatch.setenv('VP_G8_BM192', '0')
+    monkeypatch.setenv('VP_FUSE_QKV_ATTN', '0')
+    eng = VitPoseHip(shp, sd, dtype='fp16', max_batch=n)
+    ref_kp, ref_tok = eng.infer(crops), eng.tokens(crops)
+    ref_k = {f: eng.profile_kernel(f) for f in ('gemm_qkv', 'gemm_fc1', 'gemm_fc2')}
+    eng.close()
+    monkeypatch.delenv('VP_G8_BM192')
+    monkeypatch.delenv('VP_FUSE_QKV_ATTN')
+    eng = VitPoseHip(shp, sd, dtype='fp16', max_batch=n)
+    runs = [(eng.infer(crops), eng.tokens(crops)) for _ in range(3)]
+    k = {f: eng.profile_kernel(f) for f in ('gemm_qkv', 'gemm_fc1', 'gemm_fc2')}
+    eng.close()
+    print(f'[{variant} @ {n}] {ref_k} -> {k}')
+    assert 'qkvattn_kernel' in k['gemm_qkv'] and 'qkvattn_kernel' not in ref_k['gemm_qkv']
+    if n > 40:
+        assert 'G8<256, 192>' in k['gemm_fc1'] and 'G8<256, 192>' in k['gemm_fc2'] and not any('G8<256, 192>' in v for v in ref_k.values())
+    for kp, tok in runs:
+        assert np.array_equal(tok, ref_tok), f'{(tok != ref_tok).any(axis=(1, 2)).sum()} of {n} crops differ in the backbone output'
+        assert np.array_equal(kp, ref_kp)
+
+
+def test_deconv_parity_order_is_bit_identical(monkeypatch):
+    """VP_DECONV_PARITY_FAST (product-side switch): the four output parities of a deconv tile as consecutive logical blocks (same XCD: shared input
+    rows) against parity-major launch order -- the same tiles, the same arithmetic: heatmaps bit for bit, fused and un-fused head."""
+    shp, sd, _ = weights('b', 'coco')
+    for n in (48, 16):                                  # 48: deconv2 + final conv fused; 16: three launches
+        crops = synthetic_crops(n, 63, 'blobs')
+        monkeypatch.setenv('VP_DECONV_PARITY_FAST', '0')
+        eng = VitPoseHip(shp, sd, dtype='fp16', max_batch=n)
+        ref_hm, ref_kp = eng.heatmaps(crops), eng.infer(crops)
+        eng.close()
+        monkeypatch.delenv('VP_DECONV_PARITY_FAST')
+        eng = VitPoseHip(shp, sd, dtype='fp16', max_batch=n)
+        hm, kp = eng.heatmaps(crops), eng.infer(crops)
+        eng.close()
+        assert np.array_equal(hm, ref_hm) and np.array_equal(kp, ref_kp), f'n = {n}: {(hm != ref_hm).sum()} heatmap values differ'
+
+
 def test_group_matches_single_handle():
     """vp_group_* with every visible device (1 on the test box): sharded result == unsharded result, bit for bit; the
     device-side all-gather leaves all keypoints on every member."""
