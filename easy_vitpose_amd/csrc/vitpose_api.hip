@@ -101,6 +101,7 @@ struct vp_ctx {
     bool fuse_ln = true;              // LayerNorm folded into the GEMMs on both sides of it (VP_FUSE_LN=0: standalone passes)
     bool fuse_qkv_attn = true;        // head dim 64, even batches of >= 128 (pair, head) tiles: attn.qkv + attention core in one kernel (VP_FUSE_QKV_ATTN=0: two launches)
     int g8_bm192 = 3;                 // the 8-phase kernel's 192 x 256 tile is a candidate for: 1 = the residual GEMMs, 2 = the wide GEMMs
+    bool g8_cost_model = true;        // tile selection with the round-4 extensions (VP_G8_COST=0: the round-3 thresholds + the 192-row fallback)
     bool deconv_parity_fast = true;   // head: the four output parities of a deconv tile run side by side on one XCD (VP_DECONV_PARITY_FAST=0: parity-major launch order)
     float *ln_part = nullptr, *rowstat = nullptr;   // partial row statistics [M][D/64][2], (mean, rstd) [M][2]
     // fp8 mode (vp_config.dtype = VP_DTYPE_FP8; csrc/mx8.h, gemm8f.hip, quant8.hip): qkv / fc1 / fc2 on MXFP8 operands.  Token rows are
@@ -412,6 +413,49 @@ struct LnFuse {
     int* tiles_out = nullptr;         // producer: number of n-tiles written per row
 };
 
+// Tile of the 8-phase kernel for an [M, N] output (wide = 16-bit output, else residual epilogue); variant 0 = the 2-phase kernels run it.
+// A pure function of the shape: tests/test_host_logic.py walks it over every batch size through the host-only tap vp_dbg_gemm8_pick.
+//
+// A candidate QUALIFIES (round 3, measured in situ at batch 32 - 256: ViTPose-B qkv at 216 / 432 tiles -15 % / -5 %, fc2 at 216 tiles -23 %, but
+// fc1 / fc2 at 288 tiles = 56 % full +20 %; ViTPose-H fc2 at batch 128, 480 tiles: 329 -> 279 us) from 1.75 tiles per CU (448), or from 192 tiles
+// when its last round is >= 80 % full.  Round 4 (`extended`; profiles/tile_sweep_r4.txt: isolated sweep + in-situ A/B at 40 - 256 crops) adds, from
+// 7 680 rows on: a launch of ONE round from 192 tiles (fc2 at 88 crops: 198 tiles of 256 x 256, 110 -> 87 us), and a candidate whose
+// rounds x tile area is below the 2-phase kernel's rounds x work of a CU per round (two 192 x 128 workgroups per CU; one when <= 256 tiles) --
+// fc2 at 172 crops: 387 tiles of 256 x 256 = 2 rounds against 3 rounds of everything else, 200 -> 173 us.  Among the qualifying candidates the
+// cheapest rounds x area wins (192 x 256 priced x 1.08: measured 1 - 8 % behind 256 x 192 at equal rounds; ties: the larger tile); without
+// `extended` the 192 x 256 tile is only the fallback when no 256-row tile qualifies.  Where isolated and in-situ timings disagreed (fc2 at 52 / 128
+// crops, ViTPose-L at 40, -S at 256: the 2-phase kernel finds `hid` in the caches and wins by 2 - 7 % in situ) the rule follows the in-situ result.
+struct G8Pick { int variant, bm, bn; long tiles; };
+G8Pick pick_gemm8_tile(int M, int N, bool wide, int bm192_mask, long min_tiles, bool extended) {
+    struct Cand { int bm, bn, variant; };
+    static const Cand cands[3] = {{256, 256, 16}, {256, 192, 17}, {192, 256, 18}};
+    const bool ext = extended && M >= 7680;
+    const long t2 = (long)((M + 191) / 192) * ((N + 127) / 128);
+    const double cost2 = t2 <= 256 ? 24576.0 : (double)((t2 + 511) / 512) * 49152.0;
+    G8Pick pk{0, 0, 0, 0};
+    double best = 0.0;
+    bool have256 = false;
+    for (int i = 0; i < 3; ++i) {
+        const Cand& cd = cands[i];
+        if (M % cd.bm || N % cd.bn || (wide && cd.variant == 17)) continue;
+        if (cd.variant == 18 && (!(bm192_mask & (wide ? 2 : 1)) || (!ext && have256))) continue;   // round-3 behaviour: only when no 256-row tile qualifies
+        const long t = (long)(M / cd.bm) * (N / cd.bn);
+        if (t < 8) continue;
+        const long rounds = (t + 255) / 256;
+        const double f = (double)t / (double)(rounds * 256);   // share of 256 CUs x rounds that computes a tile (below 256 tiles: one workgroup per tile)
+        const double cost = (double)rounds * cd.bm * cd.bn * (cd.variant == 18 ? 1.08 : 1.0);
+        bool q = t >= min_tiles || (f >= 0.8 && t >= 192);
+        if (ext) q = q || (rounds == 1 && t >= 192) || cost < 0.95 * cost2;
+        if (!q) continue;
+        if (cd.bm == 256) have256 = true;
+        if (!pk.variant || (ext ? cost < 0.98 * best : f > (double)pk.tiles / (double)((pk.tiles + 255) / 256 * 256) + 1e-9)) {
+            pk = {cd.variant, cd.bm, cd.bn, t};
+            best = cost;
+        }
+    }
+    return pk;
+}
+
 int gemm(vp_ctx* c, int fam, int epi, const uint16_t* A, const uint16_t* W, const float* bias, void* out,
          const float* aux, int M, int N, int K, int ldo, int Hin = 0, int Win = 0, int Cin = 0, const LnFuse* ln = nullptr) {
     vp::GemmArgs g{};
@@ -459,34 +503,15 @@ int gemm(vp_ctx* c, int fam, int epi, const uint16_t* A, const uint16_t* W, cons
     if (c->gemm_variant[fam] < 0 && (c->gemm8_mask & g8bit) &&
         (epi == vp::EPI_BIAS || epi == vp::EPI_BIAS_GELU || epi == vp::EPI_BIAS_RESID_LN)) {
         const bool wide = epi != vp::EPI_BIAS_RESID_LN;
-        // tile shape: the 256-row candidate (256 x 256; for the residual GEMMs also 256 x 192) whose tile count fills the rounds of 256
-        // persistent workgroups best.  The kernel is used from 1.75 tiles per CU, or for a smaller launch when its last round is >= 80 % full
-        // (measured at batch 32 - 128: ViTPose-B qkv at 216 / 432 tiles -15 % / -5 %, fc2 at 216 tiles -23 %, but fc1 / fc2 at
-        // 288 tiles = 56 % full +20 %; ViTPose-H fc2 at batch 128, 480 tiles: 329 -> 279 us).  GEMMs no 256-row tile qualifies for
-        // (row count not a multiple of 256, or a badly filled last round) get a second chance on 192 x 256 tiles -- M is always a multiple
-        // of 192: ViTPose-L fc2 at 64 crops, 192 tiles of 256 x 256 = 75 % full -> 256 tiles of 192 x 256: +2.9 % end to end.  At equal fill the
-        // 256 x 192 tile is faster (ViTPose-B fc2 at 256 crops: 768 tiles either way, 192 x 256 +5 % slower: profiles/gemm8_bm192_r4.txt).
+        // tile shape: pick_gemm8_tile above (256 x 256; residual GEMMs also 256 x 192; 192 x 256 where the row count or the rounds ask for it)
 #ifdef VP_TOOLS
         static const long min_tiles = [] { const char* e = getenv("VP_G8_MIN_TILES"); return e ? atol(e) : 448L; }();
 #else
         const long min_tiles = 448;
 #endif
-        struct Cand { int bm, bn, variant; };
-        static const Cand cands[3] = {{256, 256, 16}, {256, 192, 17}, {192, 256, 18}};
-        int pick = -1;
-        long tiles = 0;
-        double fill = 0.0;
-        auto qualifies = [&](long t, double f) { return t >= min_tiles || (f >= 0.8 && t >= 192); };
-        for (int i = 0; i < 3; ++i) {
-            const Cand& cd = cands[i];
-            if (M % cd.bm || N % cd.bn || (wide && cd.variant == 17)) continue;
-            if (cd.variant == 18 && (!(c->g8_bm192 & (wide ? 2 : 1)) || (pick >= 0 && qualifies(tiles, fill)))) continue;   // only when no 256-row tile qualifies
-            const long t = (long)(M / cd.bm) * (N / cd.bn);
-            const double f = (double)t / (double)((t + 255) / 256 * 256);   // share of 256 CUs x rounds that computes a tile (below 256 tiles: one workgroup per tile)
-            if (f > fill + 1e-9 || (cd.variant == 18 && qualifies(t, f))) { pick = i; tiles = t; fill = f; }
-        }
-        if (pick >= 0 && qualifies(tiles, fill) && vp::gemm8_supported(epi, g, cands[pick].bn, cands[pick].bm)) {
-            g.variant = cands[pick].variant;
+        const G8Pick pk = pick_gemm8_tile(M, N, wide, c->g8_bm192, min_tiles, c->g8_cost_model);
+        if (pk.variant && vp::gemm8_supported(epi, g, pk.bn, pk.bm)) {
+            g.variant = pk.variant;
 #ifdef VP_TOOLS
             if (g.variant == 16 && wide && c->g8_deferred) g.variant = 19;
 #endif
@@ -826,6 +851,7 @@ int vp_create(vp_handle* out, const vp_config* cfg) {
     if (const char* f = getenv("VP_BLOCKED_QKV")) c->blocked_qkv = atoi(f) != 0;
     if (const char* f = getenv("VP_FUSE_QKV_ATTN")) c->fuse_qkv_attn = atoi(f) != 0;
     if (const char* f = getenv("VP_DECONV_PARITY_FAST")) c->deconv_parity_fast = atoi(f) != 0;
+    if (const char* f = getenv("VP_G8_COST")) c->g8_cost_model = atoi(f) != 0;
     if (const char* f = getenv("VP_G8_BM192")) c->g8_bm192 = atoi(f);   // mask: 1 = residual GEMMs, 2 = wide GEMMs may take the 192 x 256 tile of the 8-phase kernel (0: never)
     if (const char* f = getenv("VP_GEMM8")) c->gemm8_mask = atoi(f);   // which GEMMs may take the 8-phase kernel (1 fc2, 2 fc1, 4 qkv, 8 proj; 0 = the 2-phase kernels everywhere)
 #ifdef VP_TOOLS   // development switches of the measurement build (tools/)
@@ -1317,6 +1343,15 @@ static int group_plan(int n, int w, int maxb, std::vector<int>& offs, std::vecto
         }
     }
     return (int)offs.size();
+}
+
+// HOST ONLY: the 8-phase tile the selection rule of gemm() picks for an [M, N] output (wide: qkv / fc1; else the residual GEMMs); returns the
+// variant (0 = none: 2-phase kernels, 16 = 256 x 256, 17 = 256 x 192, 18 = 192 x 256) and its tile count
+VP_API int vp_dbg_gemm8_pick(int32_t M, int32_t N, int32_t wide, int32_t bm192_mask, int32_t* tiles) {
+    if (M <= 0 || N <= 0) return VP_ERR_INVALID;
+    const G8Pick pk = pick_gemm8_tile(M, N, wide != 0, bm192_mask & 3, 448, !(bm192_mask & 4));
+    if (tiles) *tiles = (int32_t)pk.tiles;
+    return pk.variant;
 }
 
 int vp_dbg_group_plan(int32_t n, int32_t w, int32_t maxb, int32_t* offs, int32_t* cnts, int32_t cap) {

@@ -278,6 +278,10 @@ VP_API int vp_dbg_gemm_compare(int32_t device_id, int32_t dtype, int32_t epi, in
  * per device (trailing devices short or empty).  Entry e = round * w + device: offs[e], cnts[e].  Returns the number of
  * entries (rounds * w), also when it exceeds `cap` (nothing is written beyond cap); < 0 on bad arguments. */
 VP_API int vp_dbg_group_plan(int32_t n, int32_t w, int32_t maxb, int32_t* offs, int32_t* cnts, int32_t cap);
+/* HOST ONLY: which tile of the 8-phase GEMM kernel the selection rule picks for an [M, N] output -- 0 = none (2-phase kernels), 16 = 256 x 256,
+ * 17 = 256 x 192, 18 = 192 x 256; wide != 0: 16-bit-output GEMMs (qkv, fc1), else the residual GEMMs; bm192_mask bits 1 / 2 as VP_G8_BM192, bit 4 = the
+ * round-3 thresholds (as VP_G8_COST=0); *tiles (may be NULL) = its tile count */
+VP_API int vp_dbg_gemm8_pick(int32_t M, int32_t N, int32_t wide, int32_t bm192_mask, int32_t* tiles);
 /* The two-phase schedule of a group call -- HOST ONLY, stub members: the order in which group_run would submit to (+ (member + 1)) and
  * wait for (- (member + 1)) its members for n crops on w devices of max_batch maxb.  Within every round all submissions precede the
  * first wait: no member's enqueue waits for another member's compute.  Returns the trace length (also beyond `cap`); < 0 on bad arguments. */

@@ -42,7 +42,9 @@ CASES = [
                               'gemm_fc2': 'gemm8_kernel<F16, 6, G8<256, 192>>'}),                                # fc2: 192 tiles of 256 x 256 would fill 75 % -> 256 tiles of 192 x 256
     ('h', 'wholebody', 127, 2, {'gemm_fc1': 'gemm8_kernel<F16, 1, G8<256, 192>>', 'gemm_fc2': 'gemm8_kernel<F16, 6, G8<256, 192>>'}),   # 24 384 rows: only the 192-row tile divides them
     ('b', 'coco', 85, 2, {'gemm_fc1': 'gemm8_kernel<F16, 1, G8<256, 192>>', 'gemm_fc2': 'gemm8_kernel<F16, 6, G8<256, 192>>'}),   # fc2: 255 tiles = 255 workgroups, one round (a grid that is no multiple of 8)
-    ('s', 'coco', 256, 4, {'gemm_fc1': 'gemm8_kernel<F16, 1, G8<256, 256>>'}),
+    ('s', 'coco', 256, 4, {'gemm_fc1': 'gemm8_kernel<F16, 1, G8<256, 192>>'}),   # 1536 tiles of 192 x 256 = 6 rounds against 4.5 -> 5 rounds of 256 x 256
+    ('b', 'coco', 88, 2, {'gemm_fc2': 'gemm8_kernel<F16, 6, G8<256, 256>>'}),   # 198 tiles = one round of 198 workgroups
+    ('b', 'coco', 172, 2, {'gemm_fc2': 'gemm8_kernel<F16, 6, G8<256, 256>>'}),  # 387 tiles = 2 rounds (256 x 192 / 192 x 256 / 2-phase: 3)
 ]
 
 

@@ -158,6 +158,65 @@ def test_tools_library_exports_the_measurement_entry_points():
         assert not hasattr(prod, name), f'{name} must not be in the product library'
 
 
+def test_gemm8_tile_selection_over_every_batch_size():
+    """The rule that picks the 8-phase kernel's tile (vitpose_api.hip pick_gemm8_tile, through the host-only tap vp_dbg_gemm8_pick) walked over every
+    batch size 1..640 of every model.  Invariants: a picked tile divides the matrix and the tap reports its tile count; the wide GEMMs never get the
+    192-column tile; the mask bits switch the 192-row tile off per GEMM kind; a pick is justified -- it fills its rounds (>= 448 tiles, >= 192 with a last
+    round >= 80 % full, or one round from 192 tiles) or it needs fewer rounds x tile area than the 2-phase kernel; nothing is picked below 192 tiles;
+    with the round-4 extensions off (mask bit 4) the 192-row tile appears only where no 256-row tile qualifies.  And the operating points measured in
+    round 4 (profiles/tile_sweep_r4.txt, profiles/gemm8_bm192_r4.txt) keep their kernels."""
+    lib = capi.load_library()
+    tiles = C.c_int32()
+    dims = {16: (256, 256), 17: (256, 192), 18: (192, 256)}
+
+    def pick(M, N, wide, mask=3):
+        v = lib.vp_dbg_gemm8_pick(M, N, wide, mask, C.byref(tiles))
+        return v, tiles.value
+
+    def fills(t):
+        return t >= 448 or (t >= 192 and t / (-(-t // 256) * 256) >= 0.8)
+
+    for D in (384, 768, 1024, 1280):
+        for n in range(1, 641):
+            M = 192 * n
+            for N, wide in ((3 * D, 1), (4 * D, 1), (D, 0)):
+                v, t = pick(M, N, wide)
+                v3, t3 = pick(M, N, wide, 4 | 3)                                   # round-3 thresholds + the 192-row fallback
+                v0, _ = pick(M, N, wide, 4)
+                assert v in (0, 16, 17, 18) and v3 in (0, 16, 17, 18) and v0 in (0, 16, 17)
+                assert pick(M, N, wide, 0)[0] != 18 and pick(M, N, wide, 2 if not wide else 1)[0] != 18
+                t2 = n * -(-N // 128)
+                cost2 = 24576 if t2 <= 256 else -(-t2 // 512) * 49152
+                for vv, tt in ((v, t), (v3, t3)):
+                    if vv:
+                        bm, bn = dims[vv]
+                        assert M % bm == 0 and N % bn == 0 and tt == (M // bm) * (N // bn) and tt >= 192, (D, n, N, wide, vv, tt)
+                        assert not (wide and vv == 17)
+                if v:
+                    bm, bn = dims[v]
+                    cost = -(-t // 256) * bm * bn * (1.08 if v == 18 else 1.0)
+                    assert fills(t) or (M >= 7680 and (t <= 256 or cost < 0.95 * cost2)), (D, n, N, wide, v, t)
+                if v3:
+                    assert fills(t3)
+                    if v3 == 18:
+                        assert v0 == 0, (D, n, N, wide)                                # only where no 256-row tile qualifies
+                    else:
+                        assert v3 == v0
+                if M < 7680:
+                    assert (v, t) == (v3, t3)                                          # the extensions start at 40 crops
+    # operating points (BASELINE batches and the ones measured in round 4): (variant, tiles)
+    assert pick(49152, 3072, 1) == (16, 2304) and pick(49152, 768, 0) == (17, 768)            # ViTPose-B 256: fc1, fc2
+    assert pick(24576, 5120, 1) == (16, 1920) and pick(24576, 1280, 0) == (16, 480)           # ViTPose-H 128
+    assert pick(12288, 4096, 1) == (16, 768) and pick(12288, 1024, 0) == (18, 256)            # ViTPose-L 64: fc2 on 192 x 256 (192 tiles of 256 x 256 = 75 %)
+    assert pick(12096, 4096, 1) == (18, 1008) and pick(12096, 1024, 0) == (18, 252)           # ViTPose-L 63: 252 tiles = 252 workgroups, one round
+    assert pick(16320, 3072, 1) == (18, 1020) and pick(16320, 768, 0) == (18, 255)            # ViTPose-B 85
+    assert pick(16896, 768, 0) == (16, 198) and pick(33024, 768, 0) == (16, 387)              # ViTPose-B 88 / 172: fewer rounds than anything else (+7.6 % / +5.2 %)
+    assert pick(24576, 768, 0)[0] == 0 and pick(9984, 768, 0)[0] == 0 and pick(7680, 1024, 0)[0] == 0   # ViTPose-B 128 / 52, -L 40: the 2-phase kernel wins in situ
+    assert pick(49152, 384, 0)[0] == 0                                                         # ViTPose-S 256 fc2
+    assert pick(16128, 768, 0) == (17, 252) and pick(12288, 768, 0) == (17, 192)              # ViTPose-B 84 / 64
+    assert pick(12096, 1024, 0, 0)[0] == 0 and pick(12096, 1024, 0, 2)[0] == 0 and pick(12096, 4096, 1, 1)[0] == 0   # the mask bits: 1 = residual, 2 = wide
+
+
 @pytest.mark.parametrize('n', [0, 1, 7, 64, 513])
 @pytest.mark.parametrize('w', [1, 2, 8])
 @pytest.mark.parametrize('maxb', [1, 8, 64])
