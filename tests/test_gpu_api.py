@@ -220,21 +220,25 @@ def test_fused_qkv_attention_is_bit_identical(monkeypatch, variant, dataset, dty
     assert np.array_equal(odd, ref_kp[:n - 1])
 
 
-@pytest.mark.parametrize('variant,dataset,n', [('b', 'coco', 85), ('l', 'coco_25', 63), ('b', 'coco', 26)])
-def test_192_row_tiles_and_odd_tile_counts_are_bit_identical(monkeypatch, variant, dataset, n):
+@pytest.mark.parametrize('variant,dataset,n,fc2', [('b', 'coco', 85, 'G8<256, 192>'), ('l', 'coco_25', 63, 'G8<256, 192>'), ('b', 'coco', 26, None),
+                                                     ('b', 'coco', 88, 'G8<256, 256>')])
+def test_192_row_tiles_and_odd_tile_counts_are_bit_identical(monkeypatch, variant, dataset, n, fc2):
     """Batches whose row count no 256-row tile divides (three of four batch sizes): fc1 / fc2 on the 8-phase kernel's 192 x 256 tile (VP_G8_BM192, a
     product-side switch) and launches of a tile count that is no multiple of 8 (one workgroup per tile: 255 / 252 fc2 tiles, 156 fused
-    qkv + attention tiles at 26 crops) against the 2-phase kernels: keypoints and backbone tokens bit for bit, three runs."""
+    qkv + attention tiles at 26 crops; at 88 crops fc2 as ONE round of 198 tiles of 256 x 256, a pick of the round-4 selection rule, VP_G8_COST) against the
+    kernels the round-3 rule picks: keypoints and backbone tokens bit for bit, three runs."""
     shp, sd, _ = weights(variant, dataset)
     crops = synthetic_crops(n, 61, 'blobs')
     crops[n // 2:] = synthetic_crops(n - n // 2, 62, 'noise')
     monkeypatch.setenv('VP_G8_BM192', '0')
+    monkeypatch.setenv('VP_G8_COST', '0')
     monkeypatch.setenv('VP_FUSE_QKV_ATTN', '0')
     eng = VitPoseHip(shp, sd, dtype='fp16', max_batch=n)
     ref_kp, ref_tok = eng.infer(crops), eng.tokens(crops)
     ref_k = {f: eng.profile_kernel(f) for f in ('gemm_qkv', 'gemm_fc1', 'gemm_fc2')}
     eng.close()
     monkeypatch.delenv('VP_G8_BM192')
+    monkeypatch.delenv('VP_G8_COST')
     monkeypatch.delenv('VP_FUSE_QKV_ATTN')
     eng = VitPoseHip(shp, sd, dtype='fp16', max_batch=n)
     runs = [(eng.infer(crops), eng.tokens(crops)) for _ in range(3)]
@@ -242,8 +246,8 @@ def test_192_row_tiles_and_odd_tile_counts_are_bit_identical(monkeypatch, varian
     eng.close()
     print(f'[{variant} @ {n}] {ref_k} -> {k}')
     assert 'qkvattn_kernel' in k['gemm_qkv'] and 'qkvattn_kernel' not in ref_k['gemm_qkv']
-    if n > 40:
-        assert 'G8<256, 192>' in k['gemm_fc1'] and 'G8<256, 192>' in k['gemm_fc2'] and not any('G8<256, 192>' in v for v in ref_k.values())
+    if fc2:
+        assert fc2 in k['gemm_fc2'] and fc2 not in ref_k['gemm_fc2'], (k, ref_k)
     for kp, tok in runs:
         assert np.array_equal(tok, ref_tok), f'{(tok != ref_tok).any(axis=(1, 2)).sum()} of {n} crops differ in the backbone output'
         assert np.array_equal(kp, ref_kp)
