@@ -6,6 +6,7 @@ import numpy as np
 import pytest
 
 from easy_vitpose_amd import PinnedArray, VitPoseGroup, VitPoseHip
+from easy_vitpose_amd import _capi as capi
 from easy_vitpose_amd.synth import synthetic_crops
 from helpers import weights
 
@@ -251,6 +252,54 @@ def test_192_row_tiles_and_odd_tile_counts_are_bit_identical(monkeypatch, varian
     for kp, tok in runs:
         assert np.array_equal(tok, ref_tok), f'{(tok != ref_tok).any(axis=(1, 2)).sum()} of {n} crops differ in the backbone output'
         assert np.array_equal(kp, ref_kp)
+
+
+def _tile_choice_batches(D, lo=17, hi=260):
+    """One batch size per distinct (fc1 tile, fc2 tile, rounds class, tile count a multiple of 8 or not) signature of the selection rule."""
+    import ctypes as C
+    lib = capi.load_library()
+    t = C.c_int32()
+    seen, out = set(), []
+    for n in range(lo, hi + 1):
+        sig = []
+        for N, wide in ((4 * D, 1), (D, 0)):
+            v = lib.vp_dbg_gemm8_pick(192 * n, N, wide, 3, C.byref(t))
+            sig.append((v, min(-(-t.value // 256), 3) if v else 0, (t.value % 8 != 0) if v else False))
+        sig = tuple(sig)
+        if sig not in seen:
+            seen.add(sig)
+            out.append(n)
+    return out
+
+
+def test_every_tile_choice_of_the_selection_rule_is_bit_identical():
+    """The selection rule picks different kernels from batch size to batch size (2-phase, 256 x 256, 256 x 192, 192 x 256; one, two, many rounds; tile
+    counts that are no multiple of 8).  One batch size per distinct signature of the rule (ViTPose-B, 17..260 crops): every crop of the batch must
+    equal the max_batch = 8 path (64 x 64 / 128 x 128 tiles, consumer-merged statistics) bit for bit, and the kernels must be the ones the rule names."""
+    shp, sd, _ = weights('b', 'coco')
+    batches = _tile_choice_batches(shp.embed_dim)
+    assert len(batches) >= 12, batches
+    crops = synthetic_crops(max(batches), 71, 'blobs')
+    crops[1::2] = synthetic_crops(len(crops[1::2]), 72, 'noise')
+    small = VitPoseHip(shp, sd, dtype='fp16', max_batch=8)
+    ref = small.infer(crops)
+    small.close()
+    names = {0: 'TileCfg', 16: 'G8<256, 256>', 17: 'G8<192, 256>', 18: 'G8<256, 192>'}
+    import ctypes as C
+    lib, t = capi.load_library(), C.c_int32()
+    seen = set()
+    for n in batches:
+        eng = VitPoseHip(shp, sd, dtype='fp16', max_batch=n)
+        out = eng.infer(crops[:n])
+        k1, k2 = eng.profile_kernel('gemm_fc1'), eng.profile_kernel('gemm_fc2')
+        eng.close()
+        v1 = lib.vp_dbg_gemm8_pick(192 * n, 4 * shp.embed_dim, 1, 3, C.byref(t))
+        v2 = lib.vp_dbg_gemm8_pick(192 * n, shp.embed_dim, 0, 3, C.byref(t))
+        assert names[v1] in k1 and names[v2] in k2, (n, v1, k1, v2, k2)
+        seen.add((v1, v2))
+        assert np.array_equal(out, ref[:n]), f'batch {n} ({k1} / {k2}): {(out != ref[:n]).any(axis=(1, 2)).sum()} crops differ from the max_batch = 8 path'
+    print(f'[tile choices] batches {batches}: (fc1, fc2) variants seen {sorted(seen)}')
+    assert {v for p in seen for v in p} >= {0, 16, 17, 18}
 
 
 def test_deconv_parity_order_is_bit_identical(monkeypatch):
