@@ -116,7 +116,9 @@ __global__ __launch_bounds__(512, 2) void qkvattn_kernel(QkvAttnArgs g) {
     constexpr int NKEEP = 9;                              // DMA pieces of one LA (3) + one LB (6)
     auto ktile = [&](auto Bc, auto Mc, int kA, int kB) {
         constexpr int B = decltype(Bc)::value;
-        constexpr int MODE = decltype(Mc)::value;        // 1 = first K-tile after a ring start (no wait in LA)
+        constexpr int MODE = decltype(Mc)::value;        // 1 = first K-tile after a ring start (no wait in LA); 2 / 3 = the tile's last two K-tiles:
+                                                         // nothing of this tile is left to fetch -- 2: LB issues nothing and waits for all but this LA's
+                                                         // X1 pieces; 3: no issue at all, LA drains the queue (X1 of the last K-tile)
         const char* sb = smem + B * QA::BUF;
         int fo = foff;
         asm volatile("" : "+v"(fo));
@@ -133,8 +135,9 @@ __global__ __launch_bounds__(512, 2) void qkvattn_kernel(QkvAttnArgs g) {
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) xs[j][kk] = *(const u32x4*)(sb + QA::OFF_X0 + ((xoff + j * 2048) ^ (kk << 6)));
         __builtin_amdgcn_sched_barrier(0);
-        issue(1, B ^ 1, kA);
-        if constexpr (MODE != 1) wait_vm<NKEEP>();
+        if constexpr (MODE != 3) issue(1, B ^ 1, kA);
+        if constexpr (MODE == 3) wait_vm<0>();
+        else if constexpr (MODE != 1) wait_vm<NKEEP>();
         wait_lgkm<0>();
         bar();
         __builtin_amdgcn_s_setprio(1);
@@ -154,10 +157,14 @@ __global__ __launch_bounds__(512, 2) void qkvattn_kernel(QkvAttnArgs g) {
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) xs[j][kk] = *(const u32x4*)(sb + QA::OFF_X1 + ((xoff + j * 2048) ^ (kk << 6)));
         __builtin_amdgcn_sched_barrier(0);
-        issue(2, B, kB);
-        issue(0, B, kB);
-        issue(3, B, kB);
-        wait_vm<NKEEP>();
+        if constexpr (MODE < 2) {
+            issue(2, B, kB);
+            issue(0, B, kB);
+            issue(3, B, kB);
+            wait_vm<NKEEP>();
+        } else if constexpr (MODE == 2) {
+            wait_vm<3>();   // X0 / W0 / W1 of the last K-tile (issued one LB ago) have landed; this LA's three X1 pieces stay in flight
+        }
         wait_lgkm<0>();
         bar();
         __builtin_amdgcn_s_setprio(1);
@@ -174,6 +181,8 @@ __global__ __launch_bounds__(512, 2) void qkvattn_kernel(QkvAttnArgs g) {
     };
     using M0 = std::integral_constant<int, 0>;
     using M1 = std::integral_constant<int, 1>;
+    using M2 = std::integral_constant<int, 2>;
+    using M3 = std::integral_constant<int, 3>;
     using B0 = std::integral_constant<int, 0>;
     using B1 = std::integral_constant<int, 1>;
     // start of the ring on the current tile: K-tile 0 landed and visible, X0 / W0 / W1 of K-tile 1 in flight (its X1 is issued by the first LA)
@@ -204,9 +213,10 @@ __global__ __launch_bounds__(512, 2) void qkvattn_kernel(QkvAttnArgs g) {
             ktile(B0{}, M0{}, kt + 1, kt + 2);
             ktile(B1{}, M0{}, kt + 2, kt + 3);
         }
-        // the last two K-tiles keep the issue pattern (and with it the wait counts) by fetching K-tiles 0 / 1 of this tile once more: valid, unused
-        ktile(B0{}, M0{}, nk - 1, 0);
-        ktile(B1{}, M0{}, 0, 1);
+        // the last two K-tiles fetch nothing beyond this tile (the next tile's first K-tile streams in later, under the attention phase): until
+        // round 4's end they kept the issue pattern by fetching K-tiles 0 / 1 of this tile once more -- 144 KB of dead DMA per tile
+        ktile(B0{}, M2{}, nk - 1, 0);
+        ktile(B1{}, M3{}, 0, 0);
         // operands of the epilogue (bias, row sums, this lane's 12 row statistics) are requested HERE, in front of the drain of the ring: their
         // L2 latency then hides behind the wait for the run-ahead DMAs and the two barriers instead of in front of the first LDS store
         int frow_e = frow, fg_e = fg;
