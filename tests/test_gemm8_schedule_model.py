@@ -17,7 +17,7 @@ import pytest
 SLOTS = ('X0', 'X1', 'W0', 'W1')
 
 
-def program(group, ntiles, nk, bn, epi, mut=None, bm=256):
+def program(group, ntiles, nk, bn, epi, mut=None, bm=256, fp8=False):
     """Event list of one wave group (0 = waves 0-3, 1 = waves 4-7).  Events: ('issue', slot, buf, tile, kt, pieces), ('wait', n), ('bar',),
     ('read', slot, buf, tile, kt), ('vm', n) = n other vector-memory operations (epilogue stores) entering the same in-order counter."""
     nw1 = 2 if bn == 256 else 1                       # gemm8_common.h G8<BN>: W1 is 128 (2 pieces per wave) or 64 rows (1 piece)
@@ -27,6 +27,9 @@ def program(group, ntiles, nk, bn, epi, mut=None, bm=256):
         pieces['X0'], pieces['X1'] = (2, 1) if group == 0 else (1, 2)
         nkeep = 5 + nw1                               # the same for both groups (gemm8_common.h NKEEP)
         inflight = (4 if group == 0 else 3) + nw1     # gemm8.hip wait_lb(): one LB group of THIS wave group
+    if fp8:                                           # gemm8f.hip: every X slot is followed by its scale dword, an (untracked, inline-asm) global load in the same
+        pieces['X0'] = pieces['X1'] = 3                # in-order counter: NLA = 3, NLB = 5 + NW1; the scale registers are per-wave state, program order covers them
+        nkeep, inflight = 8 + nw1, 5 + nw1
     if mut == 'nkeep+1':
         nkeep += 1
     if mut == 'inflight+1':
@@ -99,8 +102,8 @@ def program(group, ntiles, nk, bn, epi, mut=None, bm=256):
     return ev
 
 
-def check(ntiles, nk, bn, epi, mut=None, bm=256):
-    progs = [program(g, ntiles, nk, bn, epi, mut, bm) for g in (0, 1)]
+def check(ntiles, nk, bn, epi, mut=None, bm=256, fp8=False):
+    progs = [program(g, ntiles, nk, bn, epi, mut, bm, fp8) for g in (0, 1)]
     segs = []
     for p in progs:                                   # segment k of a group runs between global barriers k and k + 1
         s, cur = [], []
@@ -176,6 +179,21 @@ def test_operand_ring_of_the_192_row_tile_has_no_hazard(ntiles, nk):
 @pytest.mark.parametrize('mut', ['nkeep+1', 'inflight+1'])
 def test_the_checker_bites_on_the_192_row_tile(mut):
     assert check(3, 12, 256, 'resid_reg', mut, bm=192), f'mutation {mut} went unnoticed'
+
+
+@pytest.mark.parametrize('ntiles,nk,bn,epi', [c for c in itertools.product((1, 2, 3, 5), (4, 6, 8, 10, 24, 40), (256, 192), ('plain16', 'resid_reg', 'resid_lds'))
+                                             if (c[2] == 192) == (c[3] == 'resid_lds')])
+def test_operand_ring_of_the_mxfp8_kernel_has_no_hazard(ntiles, nk, bn, epi):
+    """gemm8f.hip: K-tiles of 128 (K = 512 .. 5120), an X slot = two DMA pieces + its scale dword in the same counted stream; 256-wide tiles store from registers
+    (qkv, fc1 -> plain16; fc2 at N = 1024 / 1280 -> resid_reg), 192-wide tiles take the LDS-staged residual epilogue"""
+    errors = check(ntiles, nk, bn, epi, fp8=True)
+    assert not errors, errors[:5]
+
+
+@pytest.mark.parametrize('mut', ['nkeep+1', 'inflight+1'])
+def test_the_checker_bites_on_the_mxfp8_kernel(mut):
+    """a count that leaves one operation too many in flight would let an MFMA read a fragment -- or a scale dword -- that has not landed"""
+    assert check(3, 6, 256, 'plain16', mut, fp8=True), f'mutation {mut} went unnoticed'
 
 
 @pytest.mark.parametrize('mut', ['nkeep+1', 'inflight+1', 'early_x1'])
