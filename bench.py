@@ -516,7 +516,10 @@ def main():
         def fam_entry(f):
             src = prof if (live and f == dom) else wprof
             steps_ = args.steps if (live and f == dom) else max(args.warmup, 1)
-            return {'what': FAMILIES[f], 'kernel': kernels[f], 'timed': 'timed region' if (live and f == dom) else 'warm-up pass',
+            what = FAMILIES[f]
+            if kernels[f].startswith('qkvattn_kernel'):   # the fused kernel is accounted under the qkv family: its flops and time include the attention core,
+                what = 'attn.qkv (+LayerNorm fold +bias) + attention core (softmax, P.V) as ONE kernel; flops = both; the `attention` family is empty'
+            return {'what': what, 'kernel': kernels[f], 'timed': 'timed region' if (live and f == dom) else 'warm-up pass',
                     'ms_per_step': round(src[f]['ms'] / steps_, 4), 'avg_launch_us': round(1e3 * src[f]['ms'] / max(src[f]['launches'], 1), 2),
                     'tflops': round(src[f]['flops'] / max(src[f]['ms'], 1e-9) / 1e9, 1),
                     'algorithmic_gbps': round(src[f]['bytes'] / max(src[f]['ms'], 1e-9) / 1e6, 1)}
@@ -550,6 +553,9 @@ def main():
             'per_rank_ms_per_step': [round(v / args.steps * 1e3, 4) for v in per_rank],
             'allgather_ms': None if ag_ms is None else round(ag_ms, 4),
         }
+        if hook:   # the engine was swapped by VP_BENCH_ENGINE (CPU tests of the launcher): the numbers above are NOT a measurement of the HIP path
+            line['engine'] = 'hook:' + hook
+            line['valid'] = False
         if args.dtype == 'fp8':
             line['mode_note'] = ('OPT-IN fp8 mode (BASELINE configs[4]): the encoder GEMMs on MXFP8 operands (e4m3 + one 2^k scale per 32 k) through the block-scaled fp8 MFMA, qkv / fc1 / attn.proj / fc2; '
                                  'attention core, head, decode as fp16.  Does NOT meet the north_star 1e-3 on confidences (peaked AP-10K checkpoint: max 3.1e-3, '

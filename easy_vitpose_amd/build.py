@@ -10,8 +10,8 @@ Two libraries from the same sources:
 
 * ``libvitpose_hip.so`` -- the PRODUCT: what ``_capi.load_library`` loads, what tests / bench / smoke run.
 * ``libvitpose_hip_tools.so`` (``--tools``, ``-DVP_TOOLS``) -- the measurement build ``tools/`` load through ``VP_HIP_LIB``:
-  ablation flags, start stagger and cycle stamps inside the GEMM kernels, the experimental tile configurations and the
-  deferred-epilogue kernel (``gemm8d.hip``), the development environment switches (``include/vitpose_hip_tools.h``).
+  ablation flags, start stagger and cycle stamps inside the GEMM kernels, the experimental tile configurations, the
+  development environment switches (``include/vitpose_hip_tools.h``).
 """
 from __future__ import annotations
 
@@ -27,7 +27,7 @@ LIBDIR = os.path.join(HERE, '_lib')
 LIB = os.path.join(LIBDIR, 'libvitpose_hip.so')
 TOOLS_LIB = os.path.join(LIBDIR, 'libvitpose_hip_tools.so')
 SOURCES = ['gemm.hip', 'gemm8.hip', 'gemm8f.hip', 'qkvattn.hip', 'quant8.hip', 'attention.hip', 'elementwise.hip', 'decode.hip', 'fp8_probe.hip', 'vitpose_api.hip']
-TOOLS_SOURCES = SOURCES + ['gemm8d.hip']
+TOOLS_SOURCES = SOURCES
 HEADERS = ['common.h', 'kernels.h', 'gemm8_common.h', 'mx8.h', os.path.join('..', '..', 'include', 'vitpose_hip.h'),
            os.path.join('..', '..', 'include', 'vitpose_hip_tools.h')]
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-fvisibility=hidden',

@@ -275,6 +275,92 @@ __global__ __launch_bounds__(256) void peak_copy_kernel(const f32x4* __restrict_
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) out[i] = in[i];
 }
 
+// HBM ceiling, calibrated properly (peak_copy_kernel above keeps ONE 16-byte load in flight per lane and reads 4.6 TB/s,
+// the guide's float4 copy 6.29).  A persistent grid walks chunks of 256 lanes x U x 16 bytes; the U loads of a chunk are issued back to
+// back (U x 16 bytes in flight per lane, each wave instruction = 1 KiB contiguous), then the U stores.  MODE 0 = copy (n float4 in, n out),
+// 1 = read only (the sum of the data is kept alive by a never-true store), 2 = write only.  NT = non-temporal loads / stores.
+template <int MODE, int U, bool NT>
+__global__ __launch_bounds__(256) void peak_stream_kernel(const u32x4* __restrict__ in, u32x4* __restrict__ out, size_t n, uint32_t* sink) {
+    const size_t chunk = (size_t)256 * U;
+    const size_t nchunks = n / chunk;
+    u32x4 keep = {0u, 0u, 0u, 0u};
+    u32x4 fill = {threadIdx.x, 1u, 2u, 3u};
+    for (size_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
+        const size_t base = c * chunk + threadIdx.x;
+        u32x4 v[U];
+        if (MODE != 2) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) v[u] = NT ? __builtin_nontemporal_load(in + base + (size_t)u * 256) : in[base + (size_t)u * 256];
+        }
+        if (MODE == 1) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) keep ^= v[u];
+        } else {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const u32x4 w = MODE == 2 ? fill : v[u];
+                if (NT) __builtin_nontemporal_store(w, out + base + (size_t)u * 256);
+                else out[base + (size_t)u * 256] = w;
+            }
+        }
+    }
+    if (MODE == 1 && (keep[0] ^ keep[1] ^ keep[2] ^ keep[3]) == 0x12345677u) sink[threadIdx.x] = keep[0];
+}
+
+// VALU issue-rate probe: per round 16 independent fp32 multiply-adds per lane as 16 v_fma_f32 (PK = 0) or as 8
+// v_pk_fma_f32 on register pairs (PK = 1); NW waves per workgroup, one workgroup per CU; nothing else in the loop.  Is the packed form a
+// throughput gain on this chip where no MFMA issues beside it (a GEMM epilogue)?
+template <int NW, int PK>
+__global__ __launch_bounds__(NW * 64, 1) void valu_probe_kernel(int iters, float* sink) {
+    typedef __attribute__((ext_vector_type(2))) float f32x2;
+    f32x2 a[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a[i] = f32x2{1.0f + 0.001f * (float)(threadIdx.x + i), 0.5f + 0.002f * (float)(threadIdx.x + i)};
+    const f32x2 m = {1.0001f, 0.9999f}, c = {0.25f, -0.25f};
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                if (PK) {
+                    asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(m), "v"(c));
+                } else {
+                    asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[i][0]) : "v"(m[0]), "v"(c[0]));
+                    asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[i][1]) : "v"(m[1]), "v"(c[1]));
+                }
+            }
+        }
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s += a[i][0] + a[i][1];
+    if (s == 12345.f) sink[threadIdx.x] = s;
+}
+
+// Where do the workgroups of a launch land?  Every workgroup records HW_REG_HW_ID, HW_REG_XCC_ID and the time it started (tools/hwid_probe.py):
+// which wave slots / CU / XCD two co-resident 512-thread workgroups of a 2-per-CU launch get.
+__global__ void hwid_probe_kernel(uint32_t* out, int spin) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (threadIdx.x == 0) {
+        const uint32_t hw = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);     // HW_REG_HW_ID, 32 bits
+        const uint32_t xcc = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 20);   // HW_REG_XCC_ID
+        const unsigned long long t = __builtin_readcyclecounter();
+        out[4 * blockIdx.x + 0] = hw;
+        out[4 * blockIdx.x + 1] = xcc;
+        out[4 * blockIdx.x + 2] = (uint32_t)t;
+        out[4 * blockIdx.x + 3] = (uint32_t)(t >> 32);
+        ((volatile char*)smem)[0] = 1;
+    }
+    for (int i = 0; i < spin; ++i) __builtin_amdgcn_s_sleep(64);   // stay resident so that the first round of workgroups fills the chip
+}
+
+hipError_t hwid_probe_launch(uint32_t* d_out, int blocks, int threads, int lds_bytes, int spin, hipStream_t s) {
+    hipError_t e = hipFuncSetAttribute((const void*)hwid_probe_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(hwid_probe_kernel, dim3(blocks), dim3(threads), lds_bytes, s, d_out, spin);
+    return hipGetLastError();
+}
+
 // LDS-DMA ceiling: every wave streams 1 KiB pieces global -> LDS (global_load_lds_dwordx4) from an L2-resident
 // source, DEPTH pieces in flight, nothing else.  blocks_per_cu x 256 threads, 64 KiB LDS ring per block.
 template <int DEPTH>
@@ -495,6 +581,53 @@ hipError_t peak_bench(int kind, double* result) {
         hipEventElapsedTime(&ms, e0, e1);
         *result = (double)ms * 1e6 / iters;
         hipFree(dst); hipFree(src); hipFree(d);
+    } else if (kind >= 300 && kind < 492) {
+        // 300 + 64 * mode (0 copy, 1 read, 2 write) + 32 * nt + 8 * ucode (U = 1, 2, 4, 8) + gridcode (workgroups = 256 x {2, 4, 8, 16, 32, 64}; 6: one per chunk; 7: 256 x 3):
+        // TB/s of algorithmic traffic (copy: bytes read + bytes written) over 1 GiB per direction
+        const int k = kind - 300, mode = k >> 6, nt = (k >> 5) & 1, uc = (k >> 3) & 3, gc = k & 7;
+        const int U = 1 << uc;
+        const size_t n = (size_t)1 << 26;   // 64 Mi x 16 bytes = 1 GiB
+        u32x4 *a = nullptr, *b = nullptr; uint32_t* d = nullptr;
+        if (mode != 2) { hipMalloc((void**)&a, n * 16); hipMemset(a, 1, n * 16); }
+        if (mode != 1) { hipMalloc((void**)&b, n * 16); hipMemset(b, 2, n * 16); }
+        hipMalloc((void**)&d, 4096);
+        const size_t nchunks = n / ((size_t)256 * U);
+        static const int gmul[8] = {2, 4, 8, 16, 32, 64, 0, 3};
+        const unsigned grid = gc == 6 ? (unsigned)nchunks : 256u * gmul[gc];
+#define VP_STREAM(M, UU, N) hipLaunchKernelGGL((peak_stream_kernel<M, UU, N>), dim3(grid), dim3(256), 0, nullptr, a, b, n, d)
+#define VP_STREAM_U(M, N) do { if (U == 1) VP_STREAM(M, 1, N); else if (U == 2) VP_STREAM(M, 2, N); else if (U == 4) VP_STREAM(M, 4, N); else VP_STREAM(M, 8, N); } while (0)
+#define VP_STREAM_N(M) do { if (nt) VP_STREAM_U(M, true); else VP_STREAM_U(M, false); } while (0)
+        float best = 1e30f;
+        for (int rep = 0; rep < 5; ++rep) {
+            hipEventRecord(e0, nullptr);
+            if (mode == 0) VP_STREAM_N(0); else if (mode == 1) VP_STREAM_N(1); else VP_STREAM_N(2);
+            hipEventRecord(e1, nullptr);
+            hipDeviceSynchronize();
+            hipEventElapsedTime(&ms, e0, e1);
+            if (rep > 0 && ms < best) best = ms;
+        }
+#undef VP_STREAM_N
+#undef VP_STREAM_U
+#undef VP_STREAM
+        *result = (mode == 0 ? 2.0 : 1.0) * n * 16 / (best * 1e-3) / 1e12;
+        if (a) hipFree(a);
+        if (b) hipFree(b);
+        hipFree(d);
+    } else if (kind >= 500 && kind < 504) {   // 500 + 2 * (two waves per SIMD) + packed: VALU probe, nanoseconds per round of 64 multiply-adds per lane
+        const int pk = (kind - 500) & 1, two = (kind - 500) >> 1;
+        float* d;
+        hipMalloc(&d, 4096);
+        const int iters = 20000;
+        for (int rep = 0; rep < 2; ++rep) {
+            hipEventRecord(e0, nullptr);
+            if (!two) { if (pk) hipLaunchKernelGGL((valu_probe_kernel<4, 1>), dim3(256), dim3(256), 0, nullptr, iters, d); else hipLaunchKernelGGL((valu_probe_kernel<4, 0>), dim3(256), dim3(256), 0, nullptr, iters, d); }
+            else { if (pk) hipLaunchKernelGGL((valu_probe_kernel<8, 1>), dim3(256), dim3(512), 0, nullptr, iters, d); else hipLaunchKernelGGL((valu_probe_kernel<8, 0>), dim3(256), dim3(512), 0, nullptr, iters, d); }
+            hipEventRecord(e1, nullptr);
+            hipDeviceSynchronize();
+        }
+        hipEventElapsedTime(&ms, e0, e1);
+        *result = (double)ms * 1e6 / iters;
+        hipFree(d);
     } else if (kind >= 3 && kind <= 12) {   // 7 .. 12: 64 / 96 / 128 / 192 / 256 / 384 MiB sources: is the 256 MB memory-side cache faster than HBM?
         static const size_t mib[] = {32, 1024, 2, 0, 64, 96, 128, 192, 256, 384};
         const size_t bytes = kind == 6 ? ((size_t)256 << 10) : (mib[kind - 3] << 20);

@@ -182,6 +182,19 @@ __global__ __launch_bounds__(C::NT, 2) void gemm_kernel(GemmArgs g) {
     }
     const int n0 = tn * C::BN, m0 = tm * C::BM;
     const int K = g.K;
+    if constexpr (LN_PROD) {
+        // experiment (tools build, VP_PROJ_STAGGER = 1000 mode + n): of the first round of workgroups (two per CU, all started together) the SECOND
+        // one of every CU starts n x 1024 cycles late, so that one workgroup of a CU is in its HBM-bound epilogue while the other runs its K-loop.
+        // mode 0: second = wave slots 2 / 3 of the SIMD (HW_REG_HW_ID), 1: blockIdx >= 256, 2: odd (blockIdx >> 3)
+        if (VP_STAGGER(g) > 0 && blockIdx.x < 512) {
+            const int mode = VP_STAGGER(g) / 1000, n = VP_STAGGER(g) % 1000;
+            bool late;
+            if (mode == 0) late = (__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) >> 1) & 1;
+            else if (mode == 1) late = blockIdx.x >= 256;
+            else late = (blockIdx.x >> 3) & 1;
+            if (late) for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(16);
+        }
+    }
 
     // ---- staging addresses: piece p of an operand = rows [(p*NWAVES + wave)*RPG, +RPG) ----
     const int rip = lane / C::SLOTS, pslot = lane % C::SLOTS;
@@ -1253,14 +1266,14 @@ static hipError_t dispatch(int epi, const GemmArgs& a, hipStream_t s) {
 int gemm_tile_bn(int variant) {
     static const int bn[NUM_TILE_CFGS] = {Cfg0::BN, Cfg1::BN, Cfg2::BN, Cfg3::BN, Cfg4::BN, Cfg5::BN, Cfg6::BN, Cfg7::BN, Cfg8::BN, Cfg9::BN, Cfg10::BN, Cfg11::BN,
                                           Cfg12::BN, Cfg13::BN, Cfg14::BN, Cfg15::BN};
-    if (variant == 16 || variant == 18 || variant == 19) return 256;
+    if (variant == 16 || variant == 18) return 256;
     if (variant == 17) return 192;
     return (variant >= 0 && variant < NUM_TILE_CFGS) ? bn[variant] : 0;
 }
 
 hipError_t gemm_launch(int dtype, int epi, const GemmArgs& a, hipStream_t s) {
     if (a.K % 64 != 0 || a.M <= 0 || a.N <= 0) return hipErrorInvalidValue;
-    if (a.variant >= 16 && a.variant <= 19) {   // 16: 256 x 256, 17: 256 x 192, 18: 192 x 256 (residual GEMMs), 19: deferred epilogue (tools build)
+    if (a.variant >= 16 && a.variant <= 18) {   // 16: 256 x 256, 17: 256 x 192, 18: 192 x 256
 #ifdef VP_TOOLS
         static const int stagger_env = [] { const char* e = getenv("VP_G8_STAGGER"); return e ? atoi(e) : -1; }();
         if (stagger_env >= 0) {
@@ -1271,6 +1284,14 @@ hipError_t gemm_launch(int dtype, int epi, const GemmArgs& a, hipStream_t s) {
 #endif
         return gemm8_launch(dtype, epi, a, a.variant == 17 ? 192 : 256, s, a.variant == 18 ? 192 : 256);
     }
+#ifdef VP_TOOLS
+    static const int proj_stagger_env = [] { const char* e = getenv("VP_PROJ_STAGGER"); return e ? atoi(e) : 0; }();
+    if (proj_stagger_env > 0 && (epi == EPI_BIAS_RESID_LN) && a.K <= a.N) {
+        GemmArgs b = a;
+        b.stagger = proj_stagger_env;
+        return dtype == DT_F16 ? dispatch<F16>(epi, b, s) : dispatch<BF16>(epi, b, s);
+    }
+#endif
     if (a.persist) {   // persistent variant: wide 16-bit-output GEMMs on the default tile (a 256x256 instantiation spilled and was slower)
         if ((epi != EPI_BIAS && epi != EPI_BIAS_GELU) || a.variant != 8 || a.K % 128 || a.N % 8 || a.ldo != a.N || a.reverse ||
             a.M % Cfg8::BM || (size_t)a.M * a.K * 2 >= (1ull << 32) ||

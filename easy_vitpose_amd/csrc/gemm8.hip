@@ -651,11 +651,6 @@ bool gemm8_supported(int epi, const GemmArgs& a, int bn, int bm) {
 
 hipError_t gemm8_launch(int dtype, int epi, const GemmArgs& a, int bn, hipStream_t s, int bm) {
     if (!gemm8_supported(epi, a, bn, bm)) return hipErrorInvalidValue;
-#ifdef VP_TOOLS
-    if (a.variant == 19) return gemm8_deferred_launch(dtype, epi, a, s);   // experimental variant, own translation unit (measured, not shipped)
-#else
-    if (a.variant == 19) return hipErrorInvalidValue;
-#endif
 #define VP_G8(TY)                                                                                                       \
     do {                                                                                                                \
         if (epi == EPI_BIAS) return bm == 192 ? launch8<TY, EPI_BIAS, G8<256, 192>>(a, s) : launch8<TY, EPI_BIAS, G8<256>>(a, s);                \

@@ -1,4 +1,4 @@
-// Shared pieces of the 8-phase GEMM kernels (gemm8.hip, gemm8d.hip): tile geometry, wait / barrier helpers, tile walk.
+// Shared pieces of the 8-phase GEMM kernels (gemm8.hip, gemm8f.hip, qkvattn.hip): tile geometry, wait / barrier helpers, tile walk.
 #pragma once
 #include <type_traits>
 #include <utility>

@@ -99,9 +99,6 @@ hipError_t gemm_launch(int dtype, int epi, const GemmArgs& a, hipStream_t s);
 // Selected through GemmArgs::variant 16 (bn 256) / 17 (bn 192) in gemm_launch.
 bool gemm8_supported(int epi, const GemmArgs& a, int bn, int bm = 256);
 hipError_t gemm8_launch(int dtype, int epi, const GemmArgs& a, int bn, hipStream_t s, int bm = 256);
-#ifdef VP_TOOLS
-hipError_t gemm8_deferred_launch(int dtype, int epi, const GemmArgs& a, hipStream_t s);   // gemm8d.hip, variant 19 (measured, not shipped)
-#endif
 // name of the kernel a launch resolves to, as the profiler prints it minus the namespace; written by the launch code when
 // GemmArgs::desc != nullptr (vp_profile_kernel)
 
@@ -135,6 +132,8 @@ hipError_t mx_probe_launch(const float* dA, const float* dW, const float* dWs, u
 
 // calibration micro-benchmarks (tools/): kind 0/1 = MFMA 16x16x32 / 32x32x16 f16 TFLOP/s, 2 = float4 copy TB/s
 hipError_t peak_bench(int kind, double* result);
+// tools/hwid_probe.py: every workgroup of a launch records (HW_REG_HW_ID, HW_REG_XCC_ID, start cycle lo, hi) -> d_out[blocks][4]
+hipError_t hwid_probe_launch(uint32_t* d_out, int blocks, int threads, int lds_bytes, int spin, hipStream_t s);
 
 // ------------------------------------------------------------------ attention
 // qkv [B*192, 3*D] 16-bit (columns = [q | k | v] x heads x head_dim, vit.py:166-167)

@@ -91,7 +91,6 @@ struct vp_ctx {
     float *hm = nullptr, *kp = nullptr, *tok = nullptr;
     float* hm_keep = nullptr;         // flip-test: heatmaps of the un-flipped crops while the flipped pass runs
     int32_t* partner = nullptr;       // flip-test: mirror joint per joint
-    bool g8_deferred = false;         // wide GEMMs on the deferred-quadrant-epilogue variant of gemm8 (VP_G8_DEFERRED=1; measured slower)
     int g8_stagger = 0;               // gemm8: start delay per XCD in sleep quanta (VP_G8_STAGGER)
     int gemm8_mask = 0x7;             // GEMMs on the 8-phase kernel at large batch: 1 fc2, 2 fc1, 4 qkv, 8 proj (VP_GEMM8; proj measured slower)
     bool persist_gemm = true;         // qkv / fc1 as persistent workgroups at large batch (VP_PERSIST=0: one tile per workgroup)
@@ -512,9 +511,6 @@ int gemm(vp_ctx* c, int fam, int epi, const uint16_t* A, const uint16_t* W, cons
         const G8Pick pk = pick_gemm8_tile(M, N, wide, c->g8_bm192, min_tiles, c->g8_cost_model);
         if (pk.variant && vp::gemm8_supported(epi, g, pk.bn, pk.bm)) {
             g.variant = pk.variant;
-#ifdef VP_TOOLS
-            if (g.variant == 16 && wide && c->g8_deferred) g.variant = 19;
-#endif
             g.group_m = fam == VP_PROF_GEMM_QKV ? 4 : fam == VP_PROF_GEMM_FC2 ? 2 : 8;   // measured sweep 0 / 2 / 4 / 8 / 16 / 32 (spread 2-3 %)
             g.persist = 0;
             g.stagger = c->g8_stagger;
@@ -659,12 +655,13 @@ int forward_chunk(vp_ctx* c, const void* d_crops, int fmt, int n, bool want_toke
             if (fold_stats) { cq.rowstat = nullptr; cq.ln_part = c->ln_part; cq.ln_tiles = D / 64; }
             // attn.qkv + attention core as ONE kernel per (pair of crops, head) from 128 tiles on (qkvattn.hip; bit-identical y; an odd batch's last crop fills both halves of its pair)
             static const long qa_min_tiles = [] { const char* e = getenv("VP_QA_MIN_TILES"); return e ? atol(e) : 128L; }();   // the fused kernel wins from 128 tiles on (measured sweep 128 - 1536 tiles: profiles/qkvattn_r4.txt)
-            if (b.w_qkvh && !fold_stats && (long)((n + 1) / 2) * c->heads >= qa_min_tiles && c->gemm_variant[VP_PROF_GEMM_QKV] < 0) {
-                vp::QkvAttnArgs qa{};
-                qa.x_hi = xh; qa.wh = b.w_qkvh; qa.bh = b.b_qkvh; qa.sh = b.s_qkvh; qa.rowstat = c->rowstat; qa.y = c->y;
-                qa.npairs = (n + 1) / 2; qa.ncrops = n; qa.heads = c->heads; qa.D = D;   // odd n: the last crop fills both halves of its pair
-                const float scale = 1.0f / sqrtf(64.0f);
-                qa.scale_log2e = scale * 1.4426950408889634f;
+            vp::QkvAttnArgs qa{};
+            qa.x_hi = xh; qa.wh = b.w_qkvh; qa.bh = b.b_qkvh; qa.sh = b.s_qkvh; qa.rowstat = c->rowstat; qa.y = c->y;
+            qa.npairs = (n + 1) / 2; qa.ncrops = n; qa.heads = c->heads; qa.D = D;   // odd n: the last crop fills both halves of its pair
+            qa.scale_log2e = (1.0f / sqrtf(64.0f)) * 1.4426950408889634f;
+            // (a shape the fused kernel rejects -- a chunk beyond its 32-bit row offsets, fewer than 8 tiles under a lowered VP_QA_MIN_TILES -- falls through
+            // to the gemm + attention pair below, the way gemm() falls back when gemm8_supported says no: ADVICE r4)
+            if (b.w_qkvh && !fold_stats && (long)((n + 1) / 2) * c->heads >= qa_min_tiles && c->gemm_variant[VP_PROF_GEMM_QKV] < 0 && vp::qkvattn_supported(qa)) {
                 char desc[96];
                 desc[0] = 0;
                 LAUNCH(c, VP_PROF_GEMM_QKV, 2.0 * M * 3.0 * D * D + 4.0 * 192 * 192 * (double)D * n, 2.0 * M * D + 2.0 * 3 * D * (double)D + 2.0 * M * D,
@@ -812,8 +809,10 @@ int vp_create(vp_handle* out, const vp_config* cfg) {
     if (cfg->depth <= 0 || cfg->num_keypoints <= 0 || cfg->num_keypoints > 1024 || cfg->max_batch <= 0)
         return fail(nullptr, VP_ERR_INVALID, "depth, num_keypoints and max_batch must be positive");
     if (cfg->dtype != VP_DTYPE_F16 && cfg->dtype != VP_DTYPE_BF16 && cfg->dtype != VP_DTYPE_FP8) return fail(nullptr, VP_ERR_INVALID, "unknown dtype");
-    if (cfg->dtype == VP_DTYPE_FP8 && (D % 256 != 0 || D < 512))
-        return fail(nullptr, VP_ERR_INVALID, "the fp8 mode needs embed_dim >= 512 and a multiple of 256 (K-tiles of 128, an even number of them): ViTPose-B / -L / -H");
+    // fp8 mode: the MXFP8 kernel has no small-tile fallback -- at the minimum padded row count (512) the narrowest GEMM (attn.proj / mlp.fc2,
+    // N = D) must still have the 8 tiles gemm8f_supported asks for: 2 x D / 192 (or / 256) >= 8 -> D >= 768.  Rejected HERE, not at infer time.
+    if (cfg->dtype == VP_DTYPE_FP8 && (D % 256 != 0 || D < 768))
+        return fail(nullptr, VP_ERR_INVALID, "the fp8 mode needs embed_dim >= 768 and a multiple of 256 (K-tiles of 128, an even number of them; >= 8 tiles per GEMM at the smallest batch): ViTPose-B / -L / -H");
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
     if (e != hipSuccess || ndev <= 0)
@@ -858,7 +857,6 @@ int vp_create(vp_handle* out, const vp_config* cfg) {
     if (const char* f = getenv("VP_BLOCKED_HID")) c->blocked_hid = atoi(f) != 0;
     if (const char* f = getenv("VP_ORDER")) c->order_mask = atoi(f);
     if (const char* f = getenv("VP_G8_STAGGER")) c->g8_stagger = atoi(f);
-    if (const char* f = getenv("VP_G8_DEFERRED")) c->g8_deferred = atoi(f) != 0;
     if (const char* t = getenv("VP_ABLATE_FAM")) {   // e.g. "2:64,1:64" = non-temporal stores in the qkv and fc1 epilogues
         int f, b, used = 0;
         while (sscanf(t, "%d:%d%n", &f, &b, &used) == 2) {
@@ -2232,8 +2230,24 @@ VP_API int vp_dbg_host_e4m3(const float* in, uint8_t* out, int64_t n) {
 }
 
 // Calibration: kind 0/1 = MFMA-only loop (16x16x32 / 32x32x16 f16) in TFLOP/s, 2 = float4 copy in TB/s (read+write).
+#ifdef VP_TOOLS
+VP_API int vp_dbg_hwid_probe(int32_t device, int32_t blocks, int32_t threads, int32_t lds_bytes, int32_t spin, uint32_t* out) {
+    if (!out || blocks <= 0 || blocks > 65536 || threads <= 0 || threads > 1024 || lds_bytes < 16 || lds_bytes > 160 * 1024 || spin < 0) return fail(nullptr, VP_ERR_INVALID, "bad argument");
+    if (hipSetDevice(device) != hipSuccess) return fail(nullptr, VP_ERR_HIP, "no HIP device");
+    uint32_t* d = nullptr;
+    if (hipMalloc((void**)&d, (size_t)blocks * 16) != hipSuccess) return fail(nullptr, VP_ERR_HIP, "hipMalloc");
+    hipError_t e = vp::hwid_probe_launch(d, blocks, threads, lds_bytes, spin, nullptr);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipMemcpy(out, d, (size_t)blocks * 16, hipMemcpyDeviceToHost);
+    hipFree(d);
+    return e == hipSuccess ? VP_OK : fail(nullptr, VP_ERR_HIP, hipGetErrorString(e));
+}
+#endif
+
 VP_API int vp_dbg_peak(int32_t device, int32_t kind, double* result) {
-    if (!result || kind < 0 || (kind > 12 && (kind < 100 || kind >= 248 || (kind >= 164 && kind < 170) || (kind >= 178 && kind < 200)))) return fail(nullptr, VP_ERR_INVALID, "bad argument");
+    const bool known = (kind >= 0 && kind <= 12) || (kind >= 100 && kind < 164) || (kind >= 170 && kind < 178) || (kind >= 200 && kind < 248) ||
+                       (kind >= 300 && kind < 492) || (kind >= 500 && kind < 504);
+    if (!result || !known) return fail(nullptr, VP_ERR_INVALID, "bad argument");
     if (hipSetDevice(device) != hipSuccess) return fail(nullptr, VP_ERR_HIP, "no HIP device");
     hipError_t e = vp::peak_bench(kind, result);
     return e == hipSuccess ? VP_OK : fail(nullptr, VP_ERR_HIP, hipGetErrorString(e));
