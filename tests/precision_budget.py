@@ -24,6 +24,8 @@ ap = argparse.ArgumentParser()
 ap.add_argument('--variant', default='s')
 ap.add_argument('--crops', type=int, default=4)
 ap.add_argument('--dtype', default='fp16')
+ap.add_argument('--full', default='', help="e.g. b/coco: the CONFIDENCE error (heatmap value at the arg-max) per rounding group on the first --crops crops of "
+                "that BASELINE configuration's full-batch golden workload (peaked checkpoint, tests/golden/cases.fullbatch_crops)")
 args = ap.parse_args()
 DT = torch.float16 if args.dtype == 'fp16' else torch.bfloat16
 
@@ -66,6 +68,39 @@ def fwd(sd, x, depth, heads, on):
         x = r(F.relu(F.conv_transpose2d(x, wf, bf, stride=2, padding=1)), tag + '_out')
     return F.conv2d(x, r(sd['keypoint_head.final_layer.weight'], 'final_w'), sd['keypoint_head.final_layer.bias'])
 
+
+if args.full:
+    # which rounding point owns the 9.6e-4 confidence error of the full-batch goldens?  Confidence = the heatmap's maximum per joint
+    # (top_down_eval.py:82-114), so its error is the heatmap error AT the peak: evaluated there, per joint, one rounding group at a time.
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden'))
+    from cases import fullbatch_crops, fullbatch_plan
+    variant, dataset = args.full.split('/')
+    n_full = {(v, d): n for v, d, n in fullbatch_plan()}[(variant, dataset)]
+    with torch.no_grad():
+        shp = model_shape(variant, dataset)
+        sd = O.to_torch_state_dict(synthetic_state_dict(shp, 0, peaked=True))
+        crops = fullbatch_crops(n_full)[:args.crops]
+        x = torch.from_numpy(np.concatenate([O.pre_img(c)[0] for c in crops]))
+
+        def conf(on):
+            hm = torch.cat([fwd(sd, x[i:i + 4], shp.depth, shp.num_heads, on) for i in range(0, len(x), 4)])
+            return hm.flatten(2).max(-1).values.numpy().astype(np.float64)
+        ref = conf(set())
+        full = conf(set(GROUPS)) - ref
+        print(f'{args.full}: {full.size} joints of the first {len(x)} crops of the {n_full}-crop golden workload, peaked checkpoint, {args.dtype}: confidences '
+              f'{ref.min():.3f} .. {ref.max():.3f}; all roundings on: confidence error rms {np.sqrt((full ** 2).mean()):.3e} max {np.abs(full).max():.3e}')
+        rows = []
+        for g in GROUPS:
+            e = conf({g}) - ref
+            rows.append((float((e ** 2).mean()), float(np.abs(e).max()), g))
+        ssum = sum(v for v, _, _ in rows)
+        for v, mx, g in sorted(rows, reverse=True):
+            print(f'  {g:14s} rms {v ** 0.5:.3e}  max {mx:.3e}  {100 * v / ssum:5.1f} % of the summed variance')
+        print(f'  sum of single-group variances / all-on variance = {ssum / float((full ** 2).mean()):.2f}')
+        wsum = sum(v for v, _, g in rows if g.endswith('_w'))
+        print(f'  weight roundings {100 * wsum / ssum:.1f} %, activation roundings {100 * (1 - wsum / ssum):.1f} %; head (lastnorm_out .. final_w) '
+              f'{100 * sum(v for v, _, g in rows if g in ("lastnorm_out", "d1_w", "d1_out", "d2_w", "d2_out", "final_w")) / ssum:.1f} %')
+    sys.exit(0)
 
 with torch.no_grad():
     shp = model_shape(args.variant, 'coco')
