@@ -146,14 +146,27 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
 // minimax fit of -log2(erfc(t / sqrt 2)) / t: one transcendental + 9 VALU instructions, |error| <= 1.2e-6 in fp32 (far below the 16-bit
 // rounding of the result).  The factor 1/2 rides in the exponent (2^(-t P - 1)): one multiplication less than the round-2 form.
 // ONE definition for every GEMM kernel: the fc1 configurations must agree bit for bit.
-__device__ __forceinline__ float gelu_erf(float x) {
+// Round 5: gelu_sat<T> = the same value already SATURATED to T's range, so that the 16-bit conversion behind it needs no clamp of its own (pack2_nosat):
+// GELU(x) >= -0.17, and for x > 65504 the erfc term has underflowed to 0, so min(GELU(x), 65504) == GELU with max(x, 0) replaced by
+// med3(x, 0, 65504) -- ONE instruction for the max and the clamp (the fc1 epilogue is VALU-issue-bound: 11.5 -> 10.5 instructions per value;
+// a degree-3 fit was rejected: |error| 5e-5, the size of the 16-bit rounding of the result).  Bit-identical to pack2<T>(gelu_erf(x)) for every finite x.
+__device__ __forceinline__ float gelu_core(float x, float relu) {
     const float a = fabsf(x);
     float q = fmaf(a, 5.204574411e-04f, -7.397505390e-03f);
     q = fmaf(q, a, 5.256122897e-02f);
     q = fmaf(q, a, 4.592546873e-01f);
     q = fmaf(q, a, 1.151091354e+00f);
     const float h = __builtin_amdgcn_exp2f(fmaf(-q, a, -1.0f));
-    return fmaf(-a, h, fmaxf(x, 0.f));
+    float r = fmaf(-a, h, relu);
+    // the fp32 result is pinned here: with a saturation-free conversion directly behind it hipcc fused this multiply-add and the conversion into
+    // v_fma_mixlo/hi_f16 -- ONE rounding instead of two -- in SOME instantiations (gemm8's bias variant, not its LayerNorm variant): 17 of 37 M
+    // fc1 outputs then differed between tile configurations, whose bit identity is the race screen (tests/test_gpu_gemm_cfgs.py)
+    asm("" : "+v"(r));
+    return r;
 }
+__device__ __forceinline__ float gelu_erf(float x) { return gelu_core(x, fmaxf(x, 0.f)); }
+template <class T> __device__ __forceinline__ float gelu_sat(float x);
+template <> __device__ __forceinline__ float gelu_sat<F16>(float x) { return gelu_core(x, __builtin_amdgcn_fmed3f(x, 0.f, 65504.f)); }
+template <> __device__ __forceinline__ float gelu_sat<BF16>(float x) { return gelu_erf(x); }   // bf16 conversions never clamp
 
 }  // namespace vp

@@ -185,12 +185,17 @@ __global__ __launch_bounds__(C::NT, 2) void gemm_kernel(GemmArgs g) {
     if constexpr (LN_PROD) {
         // experiment (tools build, VP_PROJ_STAGGER = 1000 mode + n): of the first round of workgroups (two per CU, all started together) the SECOND
         // one of every CU starts n x 1024 cycles late, so that one workgroup of a CU is in its HBM-bound epilogue while the other runs its K-loop.
-        // mode 0: second = wave slots 2 / 3 of the SIMD (HW_REG_HW_ID), 1: blockIdx >= 256, 2: odd (blockIdx >> 3)
+        // mode 0: second = wave slots 2 / 3 of the SIMD (HW_REG_HW_ID), 1: blockIdx >= 256, 2: odd (blockIdx >> 3); whole CUs late (both workgroups):
+        // 3: odd CU id, 4: odd XCD, 5: odd shader engine
         if (VP_STAGGER(g) > 0 && blockIdx.x < 512) {
             const int mode = VP_STAGGER(g) / 1000, n = VP_STAGGER(g) % 1000;
+            const uint32_t hw = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);
             bool late;
-            if (mode == 0) late = (__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) >> 1) & 1;
+            if (mode == 0) late = (hw >> 1) & 1;
             else if (mode == 1) late = blockIdx.x >= 256;
+            else if (mode == 3) late = (hw >> 8) & 1;
+            else if (mode == 4) late = blockIdx.x & 1;
+            else if (mode == 5) late = (hw >> 13) & 1;
             else late = (blockIdx.x >> 3) & 1;
             if (late) for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(16);
         }
@@ -789,7 +794,7 @@ __global__ __launch_bounds__(C::NT, 2) void gemm_kernel(GemmArgs g) {
                     }
                     if (EPI == EPI_BIAS_GELU) {
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+                        for (int r = 0; r < 4; ++r) v[r] = gelu_sat<T>(v[r]);
                     }
                     if (EPI == EPI_DECONV) {
 #pragma unroll
@@ -797,8 +802,13 @@ __global__ __launch_bounds__(C::NT, 2) void gemm_kernel(GemmArgs g) {
                     }
                     if (ES == 2) {
                         u32x2 o;
-                        o[0] = pack2<T>(v[0], v[1]);
-                        o[1] = pack2<T>(v[2], v[3]);
+                        if (EPI == EPI_BIAS_GELU) {   // already saturated (common.h::gelu_sat)
+                            o[0] = pack2_nosat<T>(v[0], v[1]);
+                            o[1] = pack2_nosat<T>(v[2], v[3]);
+                        } else {
+                            o[0] = pack2<T>(v[0], v[1]);
+                            o[1] = pack2<T>(v[2], v[3]);
+                        }
                         *(u32x2*)(lrow + i * 16 * ES) = o;
                     } else {
                         *(f32x4*)(lrow + i * 16 * ES) = v;
@@ -1087,13 +1097,16 @@ __global__ __launch_bounds__(C::NT, 2) void gemm_persist_kernel(GemmArgs g) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) v[r] = ln_fold(v[r], mu, ln_s4[i][r], rs, bias4[i][r]);
                     }
+                    u32x2 o;
                     if (EPI == EPI_BIAS_GELU) {
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+                        for (int r = 0; r < 4; ++r) v[r] = gelu_sat<T>(v[r]);
+                        o[0] = pack2_nosat<T>(v[0], v[1]);
+                        o[1] = pack2_nosat<T>(v[2], v[3]);
+                    } else {
+                        o[0] = pack2<T>(v[0], v[1]);
+                        o[1] = pack2<T>(v[2], v[3]);
                     }
-                    u32x2 o;
-                    o[0] = pack2<T>(v[0], v[1]);
-                    o[1] = pack2<T>(v[2], v[3]);
                     *(u32x2*)(lrow + i * 32) = o;
                 }
             }

@@ -444,12 +444,15 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs g) {
                         } else {
                             v += bias4[f];
                         }
-                        if (EPI == EPI_BIAS_GELU) {
+                        if (EPI == EPI_BIAS_GELU) {   // saturated by gelu_sat: no clamp in the conversion (one VALU instruction per value less: the epilogue is VALU-issue-bound)
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+                            for (int r = 0; r < 4; ++r) v[r] = gelu_sat<T>(v[r]);
+                            o[2 * f] = pack2_nosat<T>(v[0], v[1]);
+                            o[2 * f + 1] = pack2_nosat<T>(v[2], v[3]);
+                        } else {
+                            o[2 * f] = pack2<T>(v[0], v[1]);
+                            o[2 * f + 1] = pack2<T>(v[2], v[3]);
                         }
-                        o[2 * f] = pack2<T>(v[0], v[1]);
-                        o[2 * f + 1] = pack2<T>(v[2], v[3]);
                     }
                     uint16_t* dst = obase + (size_t)(J / MJ) * step128 + (size_t)(J % MJ) * step16;
                     if constexpr (C::BM != 256) {   // 192-row tiles: a wave's 48 rows of an X half straddle 64-row blocks -- blocked output addressed row by row
