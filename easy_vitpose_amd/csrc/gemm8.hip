@@ -62,6 +62,15 @@
 
 namespace vp {
 
+namespace {
+__device__ __forceinline__ u32x2 lds_tr16(const char* p) {   // ds_read_b64_tr_b16: column i of a [4 keys][16 d] block to lane i of a 16-lane group
+    typedef __attribute__((__vector_size__(4 * sizeof(__fp16)))) __fp16 h4;
+    typedef __attribute__((address_space(3))) h4* lds_h4;
+    const h4 v = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_h4)(p));
+    return __builtin_bit_cast(u32x2, v);
+}
+}  // namespace
+
 // EPI: EPI_BIAS / EPI_BIAS_GELU (16-bit output straight from registers, optional LayerNorm-consumer fold, optional
 // 64x64-blocked output) or EPI_BIAS_RESID_LN (two-plane residual stream + row statistics, staged through LDS).
 template <class T, int EPI, class C>
@@ -70,6 +79,9 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs g) {
     // residual epilogue: 256-wide tiles take it straight from registers (a lane's 16 accumulator columns of a row are 16 consecutive
     // output columns and the four lanes of a row are exactly one 64-column statistics granule); 192-wide tiles stage through LDS
     constexpr bool RESID_LDS = RESID && C::BN != 256;
+    constexpr bool QKVA = (EPI == EPI_QKV_ATTN);      // attn.qkv of one crop x one head (head dim 80) + the attention core: needs the whole LDS behind the K-loop
+    constexpr bool DRAIN = RESID_LDS || QKVA;         // epilogues that drain the operand ring and restart it on the next tile
+    static_assert(!QKVA || (C::BM == 192 && C::BN == 256), "the fused qkv + attention epilogue is written for the 192 x 256 tile");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -322,8 +334,142 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs g) {
         // at the end.  One barrier apart and with no barrier inside it, the epilogues of the two groups ran one AFTER the other -- each
         // wave alone on its SIMD, held ~350 cycles by every 1 KiB store instruction (16 per wave) with nobody to issue beside it.
         // (round 3: fc1 -4.6 %, qkv -2.5 %, bit-identical; profiles/gemm8_sched_r3.txt)
-        if constexpr (!RESID_LDS) { if (!wr) bar(); }
-        if constexpr (RESID && !RESID_LDS) {
+        if constexpr (!DRAIN) { if (!wr) bar(); }
+        if constexpr (QKVA) {
+            // ---- attn.qkv epilogue + attention core for ONE crop x ONE head of head dim 80 (ViTPose-H) ----
+            // Tile columns (the head-major weight copy, qkvattn.hip::qkv_head_major80_kernel): [0, 80) = q, [80, 160) = k, [160, 240) = v, [240, 256) = zero
+            // rows.  Lane (fg_e, frow_e) holds for fragment f and row group J the four columns  c0 .. c0 + 3,  c0 = wc 64 + (f >> 1) 32 + fg_e 8 + (f & 1) 4
+            // (the SPLIT placement of the 16-bit epilogues), of token row  wr 48 + rowJ(J) + frow_e  of the crop.
+            //   1. LayerNorm fold + bias (common.h::ln_fold: the qkv epilogue's arithmetic), rounded to 16 bit, written to LDS in the attention layouts:
+            //      Q and K as [192][160 B] rows (stride 160 B = 40 dwords: the four 16-lane service groups of a ds_read_b128 fragment read are conflict-free
+            //      without padding or swizzle), V as five [192 keys][16 d] sub-tiles (attention.hip's layout for an odd number of sub-tiles) = 90 KiB of
+            //      the 112 KiB ring, which is drained first (the K-loop's run-ahead fetches of the next tile are dropped and re-issued by ring_start below,
+            //      as in the LDS-staged residual epilogue).
+            //   2. the attention core of attention.hip<80>, instruction for instruction per query tile (S^T = K Q^T over three k-steps with the d >= 80
+            //      lanes zeroed on both operands, fp32 softmax, O^T = V^T P^T through ds_read_b64_tr_b16): 12 query tiles on 8 waves -- tiles 0-7 one per
+            //      wave, tiles 8-11 on waves 0-3 (every SIMD = waves w, w + 4 gets three tiles).  y is BIT-IDENTICAL to gemm (EPI_BIAS) + attention_launch.
+            constexpr int HD = 80, QSTR = HD * 2, K_OFF = 192 * QSTR, V_OFF = 2 * 192 * QSTR, VSUB = 192 * 32, DT = HD / 16, KS = 3;
+            static_assert(V_OFF + DT * VSUB <= C::RING, "q / k / v of one crop x one head fit the operand ring");
+            const int nbq = n0 + wc * 64 + fg_e * 8;
+            const int mrow = m0 + wr * (C::XR / 2) + frow_e;
+            f32x4 b4[4], s4[4];
+            float2 st[TJ];
+#pragma unroll
+            for (int f = 0; f < 4; ++f) {
+                b4[f] = *(const f32x4*)(g.bias + nbq + (f >> 1) * 32 + (f & 1) * 4);
+                s4[f] = *(const f32x4*)(g.ln_s + nbq + (f >> 1) * 32 + (f & 1) * 4);
+            }
+#pragma unroll
+            for (int J = 0; J < TJ; ++J) st[J] = *(const float2*)(g.rowstat + 2 * (size_t)(mrow + rowJ(J)));
+            wait_vm<0>();
+            if (!wr) bar();     // undo the stagger: both groups meet here
+            __syncthreads();    // every wave is done with the ring
+            {
+                const int lrow = wr * (C::XR / 2) + frow_e;          // token row of the crop, + rowJ(J)
+#pragma unroll
+                for (int f = 0; f < 4; ++f) {
+                    const int c0 = wc * 64 + (f >> 1) * 32 + fg_e * 8 + (f & 1) * 4;
+                    const int seg = (c0 >= HD) + (c0 >= 2 * HD) + (c0 >= 3 * HD);   // 0 q, 1 k, 2 v, 3 padding (never stored)
+                    const int d0 = c0 - seg * HD;
+                    const int rmul = seg < 2 ? QSTR : 32;
+                    const int base = seg < 2 ? seg * K_OFF + d0 * 2 : V_OFF + (d0 >> 4) * VSUB + (d0 & 15) * 2;
+#pragma unroll
+                    for (int J = 0; J < TJ; ++J) {
+                        f32x4 v;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = ln_fold(acc[f][J][e], st[J].x, s4[f][e], st[J].y, b4[f][e]);
+                        const u32x2 o = {pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3])};
+                        if (seg < 3) *(u32x2*)(smem + base + (lrow + rowJ(J)) * rmul) = o;
+                    }
+                }
+            }
+            __syncthreads();
+            {
+                const char* Qs = smem;
+                const char* Ks = smem + K_OFF;
+                const char* Vs = smem + V_OFF;
+                int fr = frow, fgq = fg;
+                asm volatile("" : "+v"(fr), "+v"(fgq));
+                // 16-byte slot of k-step kk: kk 4 + fg; the d >= 80 lanes of k-step 2 (fg 2, 3) read the slot of lane fg - 2 (a broadcast: no bank conflict) and are zeroed
+                const bool live2 = fgq < 2;
+                const int slot2 = (live2 ? 8 + fgq : 6 + fgq) * 16;
+                const char* vfrag = Vs + (fgq * 4 + (fr >> 2)) * 32 + (fr & 3) * 8;
+                uint16_t* ybase = (uint16_t*)g.out + (size_t)m0 * K + (n0 >> 8) * HD;
+                const float scale_log2e = g.attn_scale_log2e;
+                for (int pass = 0; pass < 2; ++pass) {
+                    const int qt = pass * 8 + wave;
+                    if (qt >= 12) break;
+                    u32x4 qf[KS];
+                    {
+                        const char* qrow = Qs + (qt * 16 + fr) * QSTR;
+                        qf[0] = *(const u32x4*)(qrow + fgq * 16);
+                        qf[1] = *(const u32x4*)(qrow + (4 + fgq) * 16);
+                        qf[2] = *(const u32x4*)(qrow + slot2);
+                        if (!live2) qf[2] = u32x4{0u, 0u, 0u, 0u};
+                    }
+                    f32x4 sc[12];
+#pragma unroll
+                    for (int kt = 0; kt < 12; ++kt) sc[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int kt = 0; kt < 12; ++kt) {
+                        const char* krow = Ks + (kt * 16 + fr) * QSTR;
+                        const u32x4 k0 = *(const u32x4*)(krow + fgq * 16);
+                        const u32x4 k1 = *(const u32x4*)(krow + (4 + fgq) * 16);
+                        u32x4 k2 = *(const u32x4*)(krow + slot2);
+                        if (!live2) k2 = u32x4{0u, 0u, 0u, 0u};
+                        sc[kt] = mfma16<T>(k0, qf[0], sc[kt]);
+                        sc[kt] = mfma16<T>(k1, qf[1], sc[kt]);
+                        sc[kt] = mfma16<T>(k2, qf[2], sc[kt]);
+                    }
+                    float mx = -3.0e38f;
+#pragma unroll
+                    for (int kt = 0; kt < 12; ++kt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) mx = fmaxf(mx, sc[kt][r]);
+                    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+                    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                    float l = 0.f;
+                    const float mb = mx * scale_log2e;
+#pragma unroll
+                    for (int kt = 0; kt < 12; ++kt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float pv = softmax_p(sc[kt][r], scale_log2e, mb);
+                            sc[kt][r] = pv;
+                            l += pv;
+                        }
+                    l += __shfl_xor(l, 16, 64);
+                    l += __shfl_xor(l, 32, 64);
+                    const float inv_l = 1.0f / l;
+                    u32x4 pf[6];
+#pragma unroll
+                    for (int kb = 0; kb < 6; ++kb) {
+                        pf[kb][0] = pack2_nosat<T>(sc[2 * kb][0], sc[2 * kb][1]);
+                        pf[kb][1] = pack2_nosat<T>(sc[2 * kb][2], sc[2 * kb][3]);
+                        pf[kb][2] = pack2_nosat<T>(sc[2 * kb + 1][0], sc[2 * kb + 1][1]);
+                        pf[kb][3] = pack2_nosat<T>(sc[2 * kb + 1][2], sc[2 * kb + 1][3]);
+                    }
+                    uint16_t* dst = ybase + (size_t)(qt * 16 + fr) * K;
+#pragma unroll
+                    for (int dp = 0; dp < DT; ++dp) {
+                        f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int kb = 0; kb < 6; ++kb) {
+                            const char* vp_ = vfrag + dp * VSUB + kb * 1024;
+                            const u32x2 lo = lds_tr16(vp_);          // keys 32 kb + 4 g + 0..3
+                            const u32x2 hi = lds_tr16(vp_ + 512);    // keys 32 kb + 16 + 4 g + 0..3
+                            o = mfma16<T>(u32x4{lo[0], lo[1], hi[0], hi[1]}, pf[kb], o);
+                        }
+                        u32x2 w;
+                        w[0] = pack2_nosat<T>(o[0] * inv_l, o[1] * inv_l);
+                        w[1] = pack2_nosat<T>(o[2] * inv_l, o[3] * inv_l);
+                        if (!(VP_ABLATE(g) & 8)) *(u32x2*)(dst + dp * 16 + fgq * 4) = w;
+                    }
+                }
+            }
+            __syncthreads();    // every wave is done reading q / k / v before the ring refills the LDS
+            if (has_next) ring_start();   // restart the ring on the next tile (the issue pointers already point at it)
+        } else if constexpr (RESID && !RESID_LDS) {
             // ---- residual epilogue straight from registers (EPI_BIAS_RESID_LN on 256 x 256 tiles) ----
             // lane (fg_e, frow_e): rows m0 + (J >> 2) 128 + wr 64 + (J & 3) 16 + frow_e, columns nb .. nb + 15 (W rows are permuted on their
             // way into LDS, see above).  v = acc + bias + (hi + lo) of the residual stream, written back as two 16-bit planes;
@@ -602,14 +748,14 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs g) {
                 }
             }
         }
-        if constexpr (!RESID_LDS) { if (wr) bar(); }   // stagger again: waves 4-7 one barrier behind waves 0-3
+        if constexpr (!DRAIN) { if (wr) bar(); }   // stagger again: waves 4-7 one barrier behind waves 0-3
         if (!has_next) break;
         t += tw.nloc;
         m0 = nm0;
         n0 = nn0;
     }
     wait_vm<0>();   // the ring's run-ahead DMAs must have landed before the LDS is released
-    if constexpr (!RESID_LDS) {
+    if constexpr (!DRAIN) {
         if (!wr) bar();   // pair the extra barrier of the staggered group
     }
 }
@@ -641,6 +787,10 @@ static hipError_t launch8(const GemmArgs& a, hipStream_t s) {
 }
 
 bool gemm8_supported(int epi, const GemmArgs& a, int bn, int bm) {
+    if (epi == EPI_QKV_ATTN)   // one crop x one head (head dim 80) per 192 x 256 tile: M = crops * 192, N = heads * 256 (head-major weights), y [M, K]
+        return bn == 256 && bm == 192 && a.M % 192 == 0 && a.N % 256 == 0 && (a.N >> 8) * 80 == a.K && a.K % 128 == 0 && a.K >= 256 && a.ldo == a.K &&
+               (size_t)a.M * a.K * 2 < (1ull << 32) && (size_t)a.w_rows * a.K * 2 < (1ull << 32) && (a.M / 192) * (a.N / 256) >= 8 && a.rowstat && a.ln_s &&
+               !a.a_blocked && !a.out_blocked && !a.reverse;
     if (epi != EPI_BIAS && epi != EPI_BIAS_GELU && epi != EPI_BIAS_RESID_LN) return false;
     if (bn != 256 && bn != 192) return false;
     if (bm != 256 && !(bm == 192 && bn == 256)) return false;   // 192-row tiles: 256 columns wide
@@ -656,6 +806,7 @@ hipError_t gemm8_launch(int dtype, int epi, const GemmArgs& a, int bn, hipStream
     if (!gemm8_supported(epi, a, bn, bm)) return hipErrorInvalidValue;
 #define VP_G8(TY)                                                                                                       \
     do {                                                                                                                \
+        if (epi == EPI_QKV_ATTN) return launch8<TY, EPI_QKV_ATTN, G8<256, 192>>(a, s);                                  \
         if (epi == EPI_BIAS) return bm == 192 ? launch8<TY, EPI_BIAS, G8<256, 192>>(a, s) : launch8<TY, EPI_BIAS, G8<256>>(a, s);                \
         if (epi == EPI_BIAS_GELU) return bm == 192 ? launch8<TY, EPI_BIAS_GELU, G8<256, 192>>(a, s) : launch8<TY, EPI_BIAS_GELU, G8<256>>(a, s);  \
         if (bm == 192) return launch8<TY, EPI_BIAS_RESID_LN, G8<256, 192>>(a, s);                                       \

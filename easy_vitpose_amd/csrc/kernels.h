@@ -33,6 +33,8 @@ enum GemmEpi {
     EPI_POS_LN = 7,         // EPI_POS        writing the two-plane residual stream + row statistics
     EPI_DECONV_FINAL = 8,   // EPI_DECONV with the final 1x1 conv (EPI_HEATMAP) fused behind it: the 256-channel activations stay in LDS,
                             // fp32 NCHW heatmaps at out2 (256 x 256 tile only: N == 256, variant 3)
+    EPI_QKV_ATTN = 9,       // gemm8.hip, 192 x 256 tiles only (round 5): attn.qkv of ONE crop x ONE head of head dim 80 (W = head-major [q | k | v | 16 zero rows],
+                            // N = heads * 256) with the LayerNorm-consumer fold, q / k / v handed to the attention core through LDS; out = y [M, K] 16-bit
 };
 enum GemmAMode { A_DENSE = 0, A_DECONV = 1 };
 
@@ -89,6 +91,7 @@ struct GemmArgs {
     // ---- fp8 mode (gemm8f.hip; csrc/mx8.h): A = MXFP8 codes in 64 x 128 blocks (at `A`) + packed E8M0 block scales, W = e4m3 codes
     // row-major [w_rows, K] (at `W`) + one fp32 scale per output channel; EPI_BIAS_GELU writes its output as MXFP8 (codes at `out`, K of the
     // consumer = ldo, scales at out_scales)
+    float attn_scale_log2e;   // EPI_QKV_ATTN: head_dim^-0.5 * log2(e)
     int parity_fast;   // deconv: 1 = the four output parities of a tile are consecutive logical blocks (same XCD, shared input rows); 0 = parity on blockIdx.y
     const uint8_t* a_scales;
     const float* w_scale;
@@ -161,6 +164,9 @@ struct QkvAttnArgs {
 bool qkvattn_supported(const QkvAttnArgs& a);
 hipError_t qkvattn_launch(int dtype, const QkvAttnArgs& a, hipStream_t s, char* desc, int desc_cap);
 hipError_t qkv_head_major_launch(const uint16_t* w, const float* b, const float* s, uint16_t* wh, float* bh, float* sh, int D, int K, hipStream_t st);
+// head dim 80 (ViTPose-H; round 5): the fused kernel is gemm8.hip's 192 x 256 tile with EPI_QKV_ATTN -- one crop x one head per tile.  Head-major copy of the
+// LayerNorm-folded qkv weights: rows h 256 + [0, 80) = q_h, [80, 160) = k_h, [160, 240) = v_h, [240, 256) = zeros; bias and row sums alike (heads * 256 entries)
+hipError_t qkv_head_major80_launch(const uint16_t* w, const float* b, const float* s, uint16_t* wh, float* bh, float* sh, int D, int K, int heads, hipStream_t st);
 
 // ---------------------------------------------------------------- elementwise
 // fp32 [M, D] -> LayerNorm(eps 1e-6) -> 16-bit [M, D] (out16) and/or fp32 (out32), either may be null.

@@ -417,6 +417,23 @@ hipError_t qkv_head_major_launch(const uint16_t* w, const float* b, const float*
     return hipGetLastError();
 }
 
+// head dim 80: rows h 256 + r of the copy = [q_h (80) | k_h (80) | v_h (80) | 16 zero rows] in their natural order (gemm8.hip places tile column c of a
+// 256-wide tile where its 16-bit epilogues expect it: the permutation is applied by the DMA source addresses there, not here)
+__global__ void qkv_head_major80_kernel(const uint16_t* __restrict__ w, const float* __restrict__ b, const float* __restrict__ s, uint16_t* __restrict__ wh,
+                                        float* __restrict__ bh, float* __restrict__ sh, int D, int K) {
+    const int dst = blockIdx.x;                           // 0 .. heads * 256 - 1
+    const int h = dst >> 8, r = dst & 255;
+    const int src = r < 240 ? (r / 80) * D + h * 80 + r % 80 : -1;
+    for (int k = threadIdx.x; k < K; k += blockDim.x) wh[(size_t)dst * K + k] = src >= 0 ? w[(size_t)src * K + k] : (uint16_t)0;
+    if (threadIdx.x == 0) { bh[dst] = src >= 0 ? b[src] : 0.f; sh[dst] = src >= 0 ? s[src] : 0.f; }
+}
+
+hipError_t qkv_head_major80_launch(const uint16_t* w, const float* b, const float* s, uint16_t* wh, float* bh, float* sh, int D, int K, int heads, hipStream_t st) {
+    if (heads * 80 != D) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(qkv_head_major80_kernel, dim3(heads * 256), dim3(256), 0, st, w, b, s, wh, bh, sh, D, K);
+    return hipGetLastError();
+}
+
 bool qkvattn_supported(const QkvAttnArgs& a) {
     if (a.D % 128 || a.D < 256 || a.heads * 64 != a.D || a.npairs <= 0 || (a.ncrops != 2 * a.npairs && a.ncrops != 2 * a.npairs - 1)) return false;
     if ((size_t)a.npairs * 384 * a.D * 2 >= (1ull << 32)) return false;   // 32-bit per-lane offsets are relative to the tile base: only the row span matters; kept conservative

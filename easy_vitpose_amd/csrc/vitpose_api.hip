@@ -661,7 +661,23 @@ int forward_chunk(vp_ctx* c, const void* d_crops, int fmt, int n, bool want_toke
             qa.scale_log2e = (1.0f / sqrtf(64.0f)) * 1.4426950408889634f;
             // (a shape the fused kernel rejects -- a chunk beyond its 32-bit row offsets, fewer than 8 tiles under a lowered VP_QA_MIN_TILES -- falls through
             // to the gemm + attention pair below, the way gemm() falls back when gemm8_supported says no: ADVICE r4)
-            if (b.w_qkvh && !fold_stats && (long)((n + 1) / 2) * c->heads >= qa_min_tiles && c->gemm_variant[VP_PROF_GEMM_QKV] < 0 && vp::qkvattn_supported(qa)) {
+            // head dim 80: one crop x one head per 192 x 256 tile of the 8-phase kernel (gemm8.hip EPI_QKV_ATTN; bit-identical y), from one full round of 256 tiles on
+            static const long qa80_min_tiles = [] { const char* e = getenv("VP_QA80_MIN_TILES"); return e ? atol(e) : 256L; }();
+            vp::GemmArgs g80{};
+            if (b.w_qkvh && c->heads * 80 == D) {
+                g80.A = xh; g80.W = b.w_qkvh; g80.bias = b.b_qkvh; g80.ln_s = b.s_qkvh; g80.rowstat = c->rowstat; g80.out = c->y;
+                g80.M = M; g80.N = c->heads * 256; g80.K = D; g80.ldo = D; g80.w_rows = c->heads * 256; g80.variant = 18; g80.group_m = 0;
+                g80.attn_scale_log2e = (1.0f / sqrtf(80.0f)) * 1.4426950408889634f;
+                g80.ablate = c->gemm_ablate | c->fam_ablate[VP_PROF_GEMM_QKV];
+            }
+            if (g80.A && !fold_stats && (long)n * c->heads >= qa80_min_tiles && c->gemm_variant[VP_PROF_GEMM_QKV] < 0 && vp::gemm8_supported(vp::EPI_QKV_ATTN, g80, 256, 192)) {
+                char desc[192];
+                desc[0] = 0;
+                g80.desc = desc; g80.desc_cap = (int)sizeof(desc);
+                LAUNCH(c, VP_PROF_GEMM_QKV, 2.0 * M * 3.0 * D * D + 4.0 * 192 * 192 * (double)D * n, 2.0 * M * D + 2.0 * 3 * D * (double)D + 2.0 * M * D,
+                       vp::gemm_launch(c->dtype, vp::EPI_QKV_ATTN, g80, c->stream));
+                if (desc[0] && c->kernel_desc[VP_PROF_GEMM_QKV] != desc) c->kernel_desc[VP_PROF_GEMM_QKV] = desc;
+            } else if (b.w_qkvh && c->heads * 64 == D && !fold_stats && (long)((n + 1) / 2) * c->heads >= qa_min_tiles && c->gemm_variant[VP_PROF_GEMM_QKV] < 0 && vp::qkvattn_supported(qa)) {
                 char desc[96];
                 desc[0] = 0;
                 LAUNCH(c, VP_PROF_GEMM_QKV, 2.0 * M * 3.0 * D * D + 4.0 * 192 * 192 * (double)D * n, 2.0 * M * D + 2.0 * 3 * D * (double)D + 2.0 * M * D,
@@ -932,6 +948,10 @@ int vp_load_weights(vp_handle c, const vp_tensor_desc* tensors, int32_t n_tensor
             if (c->fuse_qkv_attn && D / c->heads == 64) {   // head-major copies for the fused qkv + attention kernel
                 if ((rc = dalloc(c, &b.w_qkvh, 3 * (size_t)D * D)) || (rc = dalloc(c, &b.b_qkvh, 3 * (size_t)D)) || (rc = dalloc(c, &b.s_qkvh, 3 * (size_t)D))) return rc;
                 HIPCHK(c, vp::qkv_head_major_launch(b.w_qkv, b.b_qkv, b.s_qkv, b.w_qkvh, b.b_qkvh, b.s_qkvh, D, D, nullptr));
+            } else if (c->fuse_qkv_attn && c->heads * 80 == D && D % 128 == 0) {   // head dim 80 (ViTPose-H): [q_h | k_h | v_h | 16 zero rows] per head (gemm8.hip EPI_QKV_ATTN)
+                const size_t rows = (size_t)c->heads * 256;
+                if ((rc = dalloc(c, &b.w_qkvh, rows * D)) || (rc = dalloc(c, &b.b_qkvh, rows)) || (rc = dalloc(c, &b.s_qkvh, rows))) return rc;
+                HIPCHK(c, vp::qkv_head_major80_launch(b.w_qkv, b.b_qkv, b.s_qkv, b.w_qkvh, b.b_qkvh, b.s_qkvh, D, D, c->heads, nullptr));
             }
             if ((rc = upload_ln_folded(c, &b.w_fc1, &b.s_fc1, &b.b_fc1, w1, b1, g2, be2, 4 * (size_t)D, D))) return rc;
         } else {
@@ -1627,6 +1647,21 @@ VP_API int vp_dbg_qkvattn(int32_t device, int32_t dtype, int32_t npairs, int32_t
         (rc = upload_f32(c, &ds, zeros.data(), 3 * (size_t)D)) || (rc = upload_f32(c, &drow, row.data(), 2 * M)) || (rc = dalloc(c, &dwh, 3 * (size_t)D * D)) ||
         (rc = dalloc(c, &dbh, 3 * (size_t)D)) || (rc = dalloc(c, &dsh, 3 * (size_t)D)) || (rc = dalloc(c, &dy, M * D)))
         return dbg_finish(c, rc);
+    if (heads * 80 == D) {   // head dim 80: gemm8.hip EPI_QKV_ATTN on the 192 x 256 tile (one crop x one head), head-major weights of heads * 256 rows
+        uint16_t* dwh80; float *dbh80, *dsh80;
+        const size_t rows = (size_t)heads * 256;
+        if ((rc = dalloc(c, &dwh80, rows * D)) || (rc = dalloc(c, &dbh80, rows)) || (rc = dalloc(c, &dsh80, rows))) return dbg_finish(c, rc);
+        hipError_t e8 = vp::qkv_head_major80_launch(dw, db, ds, dwh80, dbh80, dsh80, D, D, heads, nullptr);
+        vp::GemmArgs g80{};
+        g80.A = dx; g80.W = dwh80; g80.bias = dbh80; g80.ln_s = dsh80; g80.rowstat = drow; g80.out = dy;
+        g80.M = (int)M; g80.N = heads * 256; g80.K = D; g80.ldo = D; g80.w_rows = heads * 256; g80.variant = 18;
+        g80.attn_scale_log2e = (1.0f / sqrtf(80.0f)) * 1.4426950408889634f;
+        if (e8 == hipSuccess && !vp::gemm8_supported(vp::EPI_QKV_ATTN, g80, 256, 192)) return dbg_finish(c, fail(c, VP_ERR_INVALID, "shape not supported by the fused qkv + attention tile (head dim 80)"));
+        if (e8 == hipSuccess) e8 = vp::gemm_launch(c->dtype, vp::EPI_QKV_ATTN, g80, nullptr);
+        if (e8 == hipSuccess) e8 = hipDeviceSynchronize();
+        if (e8 != hipSuccess) return dbg_finish(c, fail(c, VP_ERR_HIP, std::string("qkvattn (head dim 80): ") + hipGetErrorString(e8)));
+        return dbg_finish(c, download16(c, dy, out, M * D));
+    }
     hipError_t e = vp::qkv_head_major_launch(dw, db, ds, dwh, dbh, dsh, D, D, nullptr);
     vp::QkvAttnArgs qa{};
     qa.x_hi = dx; qa.wh = dwh; qa.bh = dbh; qa.sh = dsh; qa.rowstat = drow; qa.y = dy; qa.npairs = npairs; qa.ncrops = 2 * npairs; qa.heads = heads; qa.D = D;

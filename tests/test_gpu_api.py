@@ -221,6 +221,32 @@ def test_fused_qkv_attention_is_bit_identical(monkeypatch, variant, dataset, dty
     assert np.array_equal(odd, ref_kp[:n - 1])
 
 
+@pytest.mark.parametrize('dtype,n', [('fp16', 32), ('fp16', 17), ('bf16', 16)])
+def test_fused_qkv_attention_head_dim_80_is_bit_identical(monkeypatch, dtype, n):
+    """ViTPose-H (head dim 80, BASELINE configs[2]'s model): attn.qkv + the attention core as ONE kernel per (crop, head) -- gemm8.hip's 192 x 256 tile with
+    EPI_QKV_ATTN: [q_h | k_h | v_h | 16 zero rows] head-major weights, q / k / v handed over through LDS, 12 query tiles on 8 waves -- against the two-launch
+    path (VP_FUSE_QKV_ATTN=0): keypoints and backbone tokens bit for bit, three runs (a ring / barrier race would show as run-to-run differences); 17 crops =
+    272 tiles = one round + 16."""
+    shp, sd, _ = weights('h', 'wholebody')
+    crops = synthetic_crops(n, 53, 'blobs')
+    crops[n // 2:] = synthetic_crops(n - n // 2, 54, 'noise')
+    monkeypatch.setenv('VP_FUSE_QKV_ATTN', '0')
+    eng = VitPoseHip(shp, sd, dtype=dtype, max_batch=n)
+    ref_kp, ref_tok = eng.infer(crops), eng.tokens(crops)
+    ref_kernel = eng.profile_kernel('gemm_qkv')
+    eng.close()
+    monkeypatch.delenv('VP_FUSE_QKV_ATTN')
+    eng = VitPoseHip(shp, sd, dtype=dtype, max_batch=n)
+    runs = [(eng.infer(crops), eng.tokens(crops)) for _ in range(3)]
+    kernel = eng.profile_kernel('gemm_qkv')
+    eng.close()
+    print(f'[h/{dtype} @ {n}] qkv family: {ref_kernel!r} vs {kernel!r}')
+    assert ', 9, G8<256, 192>' in kernel and ', 9, ' not in ref_kernel
+    for kp, tok in runs:
+        assert np.array_equal(tok, ref_tok), f'{(tok != ref_tok).any(axis=(1, 2)).sum()} of {n} crops differ in the backbone output'
+        assert np.array_equal(kp, ref_kp)
+
+
 @pytest.mark.parametrize('variant,dataset,n,fc2', [('b', 'coco', 85, 'G8<256, 192>'), ('l', 'coco_25', 63, 'G8<256, 192>'), ('b', 'coco', 26, None),
                                                      ('b', 'coco', 88, 'G8<256, 256>')])
 def test_192_row_tiles_and_odd_tile_counts_are_bit_identical(monkeypatch, variant, dataset, n, fc2):

@@ -81,6 +81,32 @@ def test_attention(dtype, D, heads):
     assert err <= tol, f'attention D={D} {dtype}: max err {err:.3e} > {tol:.3e}'
 
 
+@pytest.mark.parametrize('dtype,D,heads,npairs', [('fp16', 1280, 16, 8), ('bf16', 1280, 16, 9), ('fp16', 768, 12, 6)])
+def test_fused_qkv_attention_tap_against_the_two_kernels(dtype, D, heads, npairs):
+    """attn.qkv + attention core as ONE kernel through its parity tap: head dim 80 = gemm8.hip's 192 x 256 tile with EPI_QKV_ATTN (one crop x one head per
+    tile, round 5), head dim 64 = qkvattn.hip (one pair of crops x one head).  Against vp_dbg_gemm (epi 0) + vp_dbg_attention on the same operands BIT FOR
+    BIT (same accumulation order, same roundings, same attention arithmetic), and against float64 within the attention test's tolerance."""
+    M, hd = npairs * 384, D // heads
+    rng = np.random.default_rng(D + npairs)
+    x = round_to(rng.standard_normal((M, D), dtype=np.float32), dtype)
+    W = round_to((rng.standard_normal((3 * D, D)) * (1.5 / np.sqrt(D))).astype(np.float32), dtype)
+    bias = (0.1 * rng.standard_normal(3 * D)).astype(np.float32)
+    lib = capi.load_library()
+    fused = np.empty((M, D), np.float32)
+    capi.check(lib.vp_dbg_qkvattn(0, DT[dtype], npairs, D, heads, _ptr(x), _ptr(W), _ptr(bias), _ptr(fused)))
+    qkv = _gemm(dtype, 0, x, W, bias, None)
+    two = np.empty((M, D), np.float32)
+    capi.check(lib.vp_dbg_attention(0, DT[dtype], M // 192, D, heads, _ptr(qkv), _ptr(two)))
+    assert np.array_equal(fused, two), f'{(fused != two).sum()} of {fused.size} outputs differ from gemm + attention'
+    again = np.empty_like(fused)
+    capi.check(lib.vp_dbg_qkvattn(0, DT[dtype], npairs, D, heads, _ptr(x), _ptr(W), _ptr(bias), _ptr(again)))
+    assert np.array_equal(fused, again), 'run-to-run difference'
+    t = torch.from_numpy(qkv).double().reshape(M // 192, 192, 3, heads, hd).permute(2, 0, 3, 1, 4)
+    ref = ((t[0] * hd ** -0.5) @ t[1].transpose(-2, -1)).softmax(-1) @ t[2]
+    ref = ref.transpose(1, 2).reshape(M, D).numpy()
+    assert np.abs(fused - ref).max() <= 3 * OUT_EPS[dtype] * np.abs(ref).max()
+
+
 @pytest.mark.parametrize('dtype', ['fp16', 'bf16'])
 @pytest.mark.parametrize('M,D', [(7, 384), (192, 768), (33, 1024), (5, 1280)])
 def test_layernorm(dtype, M, D):
