@@ -212,8 +212,36 @@ __global__ __launch_bounds__(256) void ln_finalize_kernel(const float* __restric
     rowstat[2 * (size_t)m + 1] = rstd;
 }
 
+// Round 5: the same merge with a row's partials fetched UP FRONT as 16-byte loads (one memory latency instead of 2 x tiles dependent 4-byte loads 8 bytes
+// apart) and 64-thread workgroups (768 instead of 192 at 256 crops: every CU takes part).  ln_merge runs on the register copy: the same operations in the same
+// order, hence the same bits (the kernel sits between every residual GEMM and its consumer: 24 launches per ViTPose-B forward, 64 per ViTPose-H).
+template <int TILES>
+__global__ __launch_bounds__(64) void ln_finalize_kernel_t(const float* __restrict__ partials, float* __restrict__ rowstat, int M, float inv_d) {
+    static_assert(TILES % 2 == 0, "a row of partials is a whole number of 16-byte pieces");
+    const int m = blockIdx.x * 64 + threadIdx.x;
+    if (m >= M) return;
+    const f32x4* src = (const f32x4*)(partials + (size_t)m * TILES * 2);
+    float v[2 * TILES];
+#pragma unroll
+    for (int i = 0; i < TILES / 2; ++i) {
+        const f32x4 q = src[i];
+        v[4 * i] = q[0]; v[4 * i + 1] = q[1]; v[4 * i + 2] = q[2]; v[4 * i + 3] = q[3];
+    }
+    float mean, rstd;
+    ln_merge(v, TILES, inv_d, mean, rstd);
+    *(float2*)(rowstat + 2 * (size_t)m) = float2{mean, rstd};
+}
+
 hipError_t ln_finalize_launch(const float* partials, float* rowstat, int M, int tiles, int D, hipStream_t s) {
-    hipLaunchKernelGGL(ln_finalize_kernel, dim3((M + 255) / 256), dim3(256), 0, s, partials, rowstat, M, tiles, 1.0f / (float)D);
+    const float inv_d = 1.0f / (float)D;
+    const dim3 grid((M + 63) / 64), block(64);
+    switch (tiles) {   // D / 64 of ViTPose-S / -B / -L / -H; anything else: the generic kernel
+        case 6: hipLaunchKernelGGL(ln_finalize_kernel_t<6>, grid, block, 0, s, partials, rowstat, M, inv_d); break;
+        case 12: hipLaunchKernelGGL(ln_finalize_kernel_t<12>, grid, block, 0, s, partials, rowstat, M, inv_d); break;
+        case 16: hipLaunchKernelGGL(ln_finalize_kernel_t<16>, grid, block, 0, s, partials, rowstat, M, inv_d); break;
+        case 20: hipLaunchKernelGGL(ln_finalize_kernel_t<20>, grid, block, 0, s, partials, rowstat, M, inv_d); break;
+        default: hipLaunchKernelGGL(ln_finalize_kernel, dim3((M + 255) / 256), dim3(256), 0, s, partials, rowstat, M, tiles, inv_d);
+    }
     return hipGetLastError();
 }
 

@@ -214,9 +214,10 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs g) {
             for (int kk = 0; kk < 2; ++kk) if (MODE == 1 || !(VP_G8_ABL & 1)) xs[j][kk] = *(const u32x4*)(sb + C::OFF_X0 + ((xoff + j * 2048) ^ (kk << 6)));
         __builtin_amdgcn_sched_barrier(0);
         SEC(1);
-        issue(1, B ^ 1, kA);
+        if constexpr (MODE != 4) issue(1, B ^ 1, kA);
         SEC(2);
-        if constexpr (MODE != 1) wait_vm<NKEEP>();
+        if constexpr (MODE == 4) wait_vm<0>();   // last K-tile of a draining tile: nothing left to fetch, X1 of this K-tile is all that is in flight
+        else if constexpr (MODE != 1) wait_vm<NKEEP>();
         wait_lgkm<0>();
         SEC(3);
         KBAR();
@@ -243,12 +244,17 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs g) {
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) if (!(VP_G8_ABL & 1)) xs[j][kk] = *(const u32x4*)(sb + C::OFF_X1 + ((xoff + j * 2048) ^ (kk << 6)));
         __builtin_amdgcn_sched_barrier(0);
-        if (swB) set_tile(nm0, nn0);
-        issue(2, B, kB);
-        issue(0, B, kB);
-        issue(3, B, kB);
+        if constexpr (MODE < 3) {
+            if (swB) set_tile(nm0, nn0);
+            issue(2, B, kB);
+            issue(0, B, kB);
+            issue(3, B, kB);
+        }
         SEC(7);
-        if constexpr (MODE == 2) wait_lb(); else wait_vm<NKEEP>();
+        if constexpr (MODE == 2) wait_lb();
+        else if constexpr (MODE == 3) { if (wr) wait_vm<2>(); else wait_vm<1>(); }   // second-to-last K-tile of a draining tile (192-row geometry): LB fetches
+                                                                                       // nothing; X0 / W0 / W1 of the last K-tile landed, this LA's X1 pieces (1 / 2 per wave) stay in flight
+        else if constexpr (MODE < 3) wait_vm<NKEEP>();
         wait_lgkm<0>();
         SEC(8);
         KBAR();
@@ -275,6 +281,8 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs g) {
     using M0 = std::integral_constant<int, 0>;
     using M1 = std::integral_constant<int, 1>;
     using M2 = std::integral_constant<int, 2>;
+    using M3 = std::integral_constant<int, 3>;
+    using M4 = std::integral_constant<int, 4>;
     using B0 = std::integral_constant<int, 0>;
     using B1 = std::integral_constant<int, 1>;
     // (re)start of the ring on the issue tile: K-tile 0 and X0 / W0 / W1 of K-tile 1 issued, K-tile 0 landed and visible
@@ -322,8 +330,13 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs g) {
             ktile(B1{}, M0{}, kt + 2, kt + 3, false, 0, 0);
         }
         // last two K-tiles: LA(nk-2) still restages this tile's last X1; from LB(nk-2) on everything belongs to the next tile
-        ktile(B0{}, M0{}, nk - 1, 0, true, nm0, nn0);
-        ktile(B1{}, M2{}, 0, 1, false, 0, 0);
+        if constexpr (QKVA) {   // the fused qkv + attention epilogue needs the whole LDS: nothing of the next tile is fetched here (it streams in under the attention phase)
+            ktile(B0{}, M3{}, nk - 1, 0, false, 0, 0);
+            ktile(B1{}, M4{}, 0, 0, false, 0, 0);
+        } else {
+            ktile(B0{}, M0{}, nk - 1, 0, true, nm0, nn0);
+            ktile(B1{}, M2{}, 0, 1, false, 0, 0);
+        }
         if (tl) ts1 = __builtin_readcyclecounter();
 
         // ---------------- epilogue of tile (m0, n0) ----------------
@@ -348,8 +361,14 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs g) {
             //   2. the attention core of attention.hip<80>, instruction for instruction per query tile (S^T = K Q^T over three k-steps with the d >= 80
             //      lanes zeroed on both operands, fp32 softmax, O^T = V^T P^T through ds_read_b64_tr_b16): 12 query tiles on 8 waves -- tiles 0-7 one per
             //      wave, tiles 8-11 on waves 0-3 (every SIMD = waves w, w + 4 gets three tiles).  y is BIT-IDENTICAL to gemm (EPI_BIAS) + attention_launch.
-            constexpr int HD = 80, QSTR = HD * 2, K_OFF = 192 * QSTR, V_OFF = 2 * 192 * QSTR, VSUB = 192 * 32, DT = HD / 16, KS = 3;
-            static_assert(V_OFF + DT * VSUB <= C::RING, "q / k / v of one crop x one head fit the operand ring");
+            //   3. LDS: q / k / v live in the LAST 90 KiB of the CU's 160 KiB ([70 K, 160 K): Q, K, V), so ring buffer 0 and the X0 slot of buffer 1
+            //      ([0, 68 K)) are free from the barrier that ends the K-loop on: the next tile's first K-tile and X0 of its second stream in under the
+            //      fold, the LDS hand-over and the whole attention phase; W0 / W1 of K-tile 1 (which overlap Q) follow behind the attention phase, and the
+            //      first K-tile starts as after ring_start -- without a ring restart latency and without the two K-tiles of run-ahead fetches the draining
+            //      residual epilogue throws away.
+            constexpr int HD = 80, QSTR = HD * 2, VSUB = 192 * 32, DT = HD / 16, KS = 3;
+            constexpr int Q_OFF = 160 * 1024 - 2 * 192 * QSTR - DT * VSUB, K_OFF = Q_OFF + 192 * QSTR, V_OFF = K_OFF + 192 * QSTR;
+            static_assert(Q_OFF >= C::BUF + C::XH && Q_OFF % 16 == 0, "q / k / v behind ring buffer 0 and the X0 slot of buffer 1");
             const int nbq = n0 + wc * 64 + fg_e * 8;
             const int mrow = m0 + wr * (C::XR / 2) + frow_e;
             f32x4 b4[4], s4[4];
@@ -364,28 +383,43 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs g) {
             wait_vm<0>();
             if (!wr) bar();     // undo the stagger: both groups meet here
             __syncthreads();    // every wave is done with the ring
-            {
+            if (has_next) {     // the next tile's K-tile 0 (ring buffer 0) and X0 of its K-tile 1: on their way from here on
+                set_tile(nm0, nn0);
+                issue(2, 0, 0, true); issue(0, 0, 0, true); issue(3, 0, 0, true); issue(1, 0, 0, true);
+                issue(0, 1, 1, true);
+            }
+            if (!(VP_ABLATE(g) & 2)) {   // (tools: 2 = no fold / hand-over, 16 = no attention phase, 8 = no output stores)
                 const int lrow = wr * (C::XR / 2) + frow_e;          // token row of the crop, + rowJ(J)
+                // fragments 2 fp, 2 fp + 1 of a lane are EIGHT consecutive columns c0 .. c0 + 7 (never across a q / k / v boundary: 80 is a multiple of 8;
+                // inside one 16-d V sub-tile row): one 16-byte LDS store per row group instead of two 8-byte ones (the 16 token rows of a store
+                // instruction are 160 / 32 bytes apart: 2-way instead of 4-way bank conflicts -- the hand-over was LDS-store-bound)
 #pragma unroll
-                for (int f = 0; f < 4; ++f) {
-                    const int c0 = wc * 64 + (f >> 1) * 32 + fg_e * 8 + (f & 1) * 4;
+                for (int fp = 0; fp < 2; ++fp) {
+                    const int c0 = wc * 64 + fp * 32 + fg_e * 8;
                     const int seg = (c0 >= HD) + (c0 >= 2 * HD) + (c0 >= 3 * HD);   // 0 q, 1 k, 2 v, 3 padding (never stored)
                     const int d0 = c0 - seg * HD;
                     const int rmul = seg < 2 ? QSTR : 32;
-                    const int base = seg < 2 ? seg * K_OFF + d0 * 2 : V_OFF + (d0 >> 4) * VSUB + (d0 & 15) * 2;
+                    const int base = seg < 2 ? (seg ? K_OFF : Q_OFF) + d0 * 2 : V_OFF + (d0 >> 4) * VSUB + (d0 & 15) * 2;
 #pragma unroll
                     for (int J = 0; J < TJ; ++J) {
-                        f32x4 v;
+                        u32x4 o;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = ln_fold(acc[f][J][e], st[J].x, s4[f][e], st[J].y, b4[f][e]);
-                        const u32x2 o = {pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3])};
-                        if (seg < 3) *(u32x2*)(smem + base + (lrow + rowJ(J)) * rmul) = o;
+                        for (int h = 0; h < 2; ++h) {
+                            const int f = 2 * fp + h;
+                            f32x4 v;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = ln_fold(acc[f][J][e], st[J].x, s4[f][e], st[J].y, b4[f][e]);
+                            o[2 * h] = pack2<T>(v[0], v[1]);
+                            o[2 * h + 1] = pack2<T>(v[2], v[3]);
+                        }
+                        if (seg < 3) *(u32x4*)(smem + base + (lrow + rowJ(J)) * rmul) = o;
                     }
                 }
             }
-            __syncthreads();
-            {
-                const char* Qs = smem;
+            wait_lgkm<0>();
+            bar();              // q / k / v visible (a raw barrier: __syncthreads() would wait for the DMA pieces issued above)
+            if (!(VP_ABLATE(g) & 16)) {
+                const char* Qs = smem + Q_OFF;
                 const char* Ks = smem + K_OFF;
                 const char* Vs = smem + V_OFF;
                 int fr = frow, fgq = fg;
@@ -415,8 +449,8 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs g) {
                         const char* krow = Ks + (kt * 16 + fr) * QSTR;
                         const u32x4 k0 = *(const u32x4*)(krow + fgq * 16);
                         const u32x4 k1 = *(const u32x4*)(krow + (4 + fgq) * 16);
-                        u32x4 k2 = *(const u32x4*)(krow + slot2);
-                        if (!live2) k2 = u32x4{0u, 0u, 0u, 0u};
+                        const u32x4 k2 = *(const u32x4*)(krow + slot2);   // d >= 80 lanes: finite k values of lane fg - 2 against q = 0: products are exact zeros,
+                                                                          // as with attention.hip's zero-padded K rows (16-bit q / k / v are saturated: never inf)
                         sc[kt] = mfma16<T>(k0, qf[0], sc[kt]);
                         sc[kt] = mfma16<T>(k1, qf[1], sc[kt]);
                         sc[kt] = mfma16<T>(k2, qf[2], sc[kt]);
@@ -467,8 +501,18 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs g) {
                     }
                 }
             }
-            __syncthreads();    // every wave is done reading q / k / v before the ring refills the LDS
-            if (has_next) ring_start();   // restart the ring on the next tile (the issue pointers already point at it)
+            wait_lgkm<0>();
+            bar();              // every wave is done reading q / k / v before the rest of the ring refills the LDS (raw: the output stores stay in flight)
+            if (has_next) {
+                issue(2, 1, 1, true); issue(3, 1, 1, true);   // W0, W1 of K-tile 1: with X0 (issued above) ring_start's state; X1 of K-tile 1 is issued by the first LA
+                // K-tile 0 has landed once only the operations issued behind its last piece are outstanding: X0 of K-tile 1 (2 / 1 pieces), this wave's
+                // output stores (waves 0-3: two query tiles = 10, waves 4-7: 5) and the four pieces above.  The stores themselves are NOT waited for here:
+                // the first counted wait of the K-loop (LB of K-tile 0) retires them, half a K-tile later.
+                if (VP_ABLATE(g) & (8 | 16)) { if (wr) wait_vm<5>(); else wait_vm<6>(); }
+                else { if (wr) wait_vm<10>(); else wait_vm<16>(); }
+                bar();
+                if (wr) bar();   // stagger: waves 4-7 run one barrier behind waves 0-3
+            }
         } else if constexpr (RESID && !RESID_LDS) {
             // ---- residual epilogue straight from registers (EPI_BIAS_RESID_LN on 256 x 256 tiles) ----
             // lane (fg_e, frow_e): rows m0 + (J >> 2) 128 + wr 64 + (J & 3) 16 + frow_e, columns nb .. nb + 15 (W rows are permuted on their
@@ -763,7 +807,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs g) {
 template <class T, int EPI, class C>
 static hipError_t launch8(const GemmArgs& a, hipStream_t s) {
     auto kern = gemm8_kernel<T, EPI, C>;
-    constexpr int LDS = (EPI == EPI_BIAS_RESID_LN && C::BN != 256) ? ((128 * (C::BN * 4 + 16) + C::BM * (C::BN / 64) * 8) > C::RING ? (128 * (C::BN * 4 + 16) + C::BM * (C::BN / 64) * 8) : C::RING) : C::RING;
+    constexpr int LDS = (EPI == EPI_QKV_ATTN) ? 160 * 1024 : (EPI == EPI_BIAS_RESID_LN && C::BN != 256) ? ((128 * (C::BN * 4 + 16) + C::BM * (C::BN / 64) * 8) > C::RING ? (128 * (C::BN * 4 + 16) + C::BM * (C::BN / 64) * 8) : C::RING) : C::RING;
     static bool attr_done[64] = {};   // per device: the LDS opt-in is a per-device function attribute
     int dev = 0;
     (void)hipGetDevice(&dev);

@@ -1692,13 +1692,19 @@ VP_API int vp_dbg_qkvattn_bench(int32_t device, int32_t npairs, int32_t D, int32
     vp::QkvAttnArgs qa{};
     qa.x_hi = dx; qa.wh = dwh; qa.bh = dbh; qa.sh = dsh; qa.rowstat = drow; qa.y = dy; qa.npairs = npairs; qa.ncrops = 2 * npairs; qa.heads = heads; qa.D = D; qa.ablate = ablate;
     qa.scale_log2e = 0.125f * 1.4426950408889634f;
+    vp::GemmArgs g80{};   // head dim 80: gemm8.hip EPI_QKV_ATTN (heads * 256 head-major rows: the 3 D^2 buffer is larger than heads * 256 * D)
+    const bool h80 = heads * 80 == D;
+    g80.A = dx; g80.W = dwh; g80.bias = dbh; g80.ln_s = dsh; g80.rowstat = drow; g80.out = dy;
+    g80.M = (int)M; g80.N = heads * 256; g80.K = D; g80.ldo = D; g80.w_rows = heads * 256; g80.variant = 18; g80.ablate = ablate;
+    g80.attn_scale_log2e = (1.0f / sqrtf(80.0f)) * 1.4426950408889634f;
+    auto launch = [&]() { return h80 ? vp::gemm_launch(c->dtype, vp::EPI_QKV_ATTN, g80, nullptr) : vp::qkvattn_launch(c->dtype, qa, nullptr, nullptr, 0); };
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
     hipError_t e = hipSuccess;
-    for (int i = 0; i < 2 && e == hipSuccess; ++i) e = vp::qkvattn_launch(c->dtype, qa, nullptr, nullptr, 0);
+    for (int i = 0; i < 2 && e == hipSuccess; ++i) e = launch();
     hipDeviceSynchronize();
     hipEventRecord(e0, nullptr);
-    for (int i = 0; i < iters && e == hipSuccess; ++i) e = vp::qkvattn_launch(c->dtype, qa, nullptr, nullptr, 0);
+    for (int i = 0; i < iters && e == hipSuccess; ++i) e = launch();
     hipEventRecord(e1, nullptr);
     if (e == hipSuccess) e = hipDeviceSynchronize();
     float ms = 0.f;
