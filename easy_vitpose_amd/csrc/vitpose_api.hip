@@ -661,8 +661,8 @@ int forward_chunk(vp_ctx* c, const void* d_crops, int fmt, int n, bool want_toke
             qa.scale_log2e = (1.0f / sqrtf(64.0f)) * 1.4426950408889634f;
             // (a shape the fused kernel rejects -- a chunk beyond its 32-bit row offsets, fewer than 8 tiles under a lowered VP_QA_MIN_TILES -- falls through
             // to the gemm + attention pair below, the way gemm() falls back when gemm8_supported says no: ADVICE r4)
-            // head dim 80: one crop x one head per 192 x 256 tile of the 8-phase kernel (gemm8.hip EPI_QKV_ATTN; bit-identical y), from one full round of 256 tiles on
-            static const long qa80_min_tiles = [] { const char* e = getenv("VP_QA80_MIN_TILES"); return e ? atol(e) : 256L; }();
+            // head dim 80: one crop x one head per 192 x 256 tile of the 8-phase kernel (gemm8.hip EPI_QKV_ATTN; bit-identical y), from 192 tiles on
+            static const long qa80_min_tiles = [] { const char* e = getenv("VP_QA80_MIN_TILES"); return e ? atol(e) : 192L; }();   // wins from 12 crops x 16 heads on (profiles/qkvattn80_r5.txt)
             vp::GemmArgs g80{};
             if (b.w_qkvh && c->heads * 80 == D) {
                 g80.A = xh; g80.W = b.w_qkvh; g80.bias = b.b_qkvh; g80.ln_s = b.s_qkvh; g80.rowstat = c->rowstat; g80.out = c->y;

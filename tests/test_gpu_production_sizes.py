@@ -36,11 +36,11 @@ HM_MAX_ERR, HM_RMS_ERR = 4e-3, 6e-4     # fp16 budgets of tests/test_gpu_parity.
 # expected kernel families per case (substring of vp_profile_kernel): the selection rule of vitpose_api.hip gemm() at these sizes
 CASES = [
     # variant, dataset, batch, oracle crops, {family: substring}
-    ('h', 'wholebody', 128, 2, {'gemm_qkv': 'gemm8_kernel<F16, 0, G8<256, 256>>', 'gemm_fc1': 'gemm8_kernel<F16, 1, G8<256, 256>>',
+    ('h', 'wholebody', 128, 2, {'gemm_qkv': 'gemm8_kernel<F16, 9, G8<256, 192>>', 'gemm_fc1': 'gemm8_kernel<F16, 1, G8<256, 256>>',   # qkv + attention fused (head dim 80, round 5): 128 crops x 16 heads = 2048 one-crop tiles of 192 x 256
                                  'gemm_fc2': 'gemm8_kernel<F16, 6, G8<256, 256>>'}),
     ('l', 'coco_25', 64, 2, {'gemm_qkv': 'qkvattn_kernel<F16>', 'gemm_fc1': 'gemm8_kernel<F16, 1, G8<256, 256>>',   # qkv + attention fused: 32 pairs x 16 heads = 512 tiles, K = 1024
                               'gemm_fc2': 'gemm8_kernel<F16, 6, G8<256, 192>>'}),                                # fc2: 192 tiles of 256 x 256 would fill 75 % -> 256 tiles of 192 x 256
-    ('h', 'wholebody', 127, 2, {'gemm_fc1': 'gemm8_kernel<F16, 1, G8<256, 192>>', 'gemm_fc2': 'gemm8_kernel<F16, 6, G8<256, 192>>'}),   # 24 384 rows: only the 192-row tile divides them
+    ('h', 'wholebody', 127, 2, {'gemm_qkv': 'gemm8_kernel<F16, 9, G8<256, 192>>', 'gemm_fc1': 'gemm8_kernel<F16, 1, G8<256, 192>>', 'gemm_fc2': 'gemm8_kernel<F16, 6, G8<256, 192>>'}),   # 24 384 rows: only the 192-row tile divides them
     ('b', 'coco', 85, 2, {'gemm_fc1': 'gemm8_kernel<F16, 1, G8<256, 192>>', 'gemm_fc2': 'gemm8_kernel<F16, 6, G8<256, 192>>'}),   # fc2: 255 tiles = 255 workgroups, one round (a grid that is no multiple of 8)
     ('s', 'coco', 256, 4, {'gemm_fc1': 'gemm8_kernel<F16, 1, G8<256, 192>>'}),   # 1536 tiles of 192 x 256 = 6 rounds against 4.5 -> 5 rounds of 256 x 256
     ('b', 'coco', 88, 2, {'gemm_fc2': 'gemm8_kernel<F16, 6, G8<256, 256>>'}),   # 198 tiles = one round of 198 workgroups
