@@ -49,19 +49,38 @@ def q8_tensor(t, s):
     return (t / s).clamp(-F8MAX, F8MAX).to(F8).float() * s
 
 
-def fwd(sd, x, depth, heads, mode, act_scales=None, record=None):
-    """mode: 'fp32', 'fp16' (device pipeline), 'w8', 'w8a8', 'w8a8t'"""
+def q8_mx(t):
+    """MXFP8 as the fp8 mode's kernels write it (csrc/mx8.h): e4m3 codes + one power-of-two (E8M0) scale per 32 consecutive k, the block's amax scaled into [128, 256)."""
+    shp = t.shape
+    b = t.reshape(*shp[:-1], shp[-1] // 32, 32)
+    amax = b.abs().amax(-1, keepdim=True).clamp_min(2.0 ** -100)
+    s = torch.exp2(torch.floor(torch.log2(amax)) - 7.0)          # amax / s in [128, 256)
+    return ((b / s).to(F8).float() * s).reshape(shp)
+
+
+# GEMM family of each A-operand key / weight: the round-5 table "which single family on MXFP8 keeps the confidences" (VERDICT r4 item 6)
+FAMILY_OF = {'ln1': 'qkv', 'attn': 'proj', 'ln2': 'fc1', 'hid': 'fc2'}
+
+
+def fwd(sd, x, depth, heads, mode, act_scales=None, record=None, families=None):
+    """mode: 'fp32', 'fp16' (device pipeline), 'w8', 'w8a8', 'w8a8t', 'mx' (the shipped fp8 mode's formats); families: the GEMM families that run on
+    fp8 operands (default all four), the others keep fp16"""
     lo = mode != 'fp32'
     r = (lambda t: r16(t)) if lo else (lambda t: t)
-    def wq(w):      # encoder GEMM weight
-        return q8_rows(w) if mode in ('w8', 'w8a8', 'w8a8t') else r(w)
+    fams = set(FAMILY_OF.values()) if families is None else set(families)
+    def wq(w, fam):      # encoder GEMM weight
+        return q8_rows(w) if (mode in ('w8', 'w8a8', 'w8a8t', 'mx') and fam in fams) else r(w)
     def aq(a, key):  # encoder GEMM A operand
         if record is not None:
             record[key] = max(record.get(key, 0.0), float(a.abs().max()))
+        if FAMILY_OF[key] not in fams:
+            return r(a)
         if mode == 'w8a8':
             return q8_rows(a)
         if mode == 'w8a8t':
             return q8_tensor(a, act_scales[key] / F8MAX)
+        if mode == 'mx':
+            return q8_mx(a)
         return r(a)
     w = sd['backbone.patch_embed.proj.weight']
     x = F.conv2d(r(x), r(w), sd['backbone.patch_embed.proj.bias'], stride=16, padding=2)
@@ -73,17 +92,17 @@ def fwd(sd, x, depth, heads, mode, act_scales=None, record=None):
     for i in range(depth):
         p = f'backbone.blocks.{i}.'
         y = aq(F.layer_norm(x, (D,), sd[p + 'norm1.weight'], sd[p + 'norm1.bias'], eps=1e-6), 'ln1')
-        qkv = r(F.linear(y, wq(sd[p + 'attn.qkv.weight']), sd[p + 'attn.qkv.bias']))
+        qkv = r(F.linear(y, wq(sd[p + 'attn.qkv.weight'], 'qkv'), sd[p + 'attn.qkv.bias']))
         qkv = qkv.reshape(B, Hp * Wp, 3, heads, hd).permute(2, 0, 3, 1, 4)
         q, k, v = qkv[0], qkv[1], qkv[2]
         s = (q @ k.transpose(-2, -1)) * hd ** -0.5
         e = torch.exp(s - s.max(-1, keepdim=True).values)
         y = (r(e) @ v) / e.sum(-1, keepdim=True)
         y = aq(y.transpose(1, 2).reshape(B, Hp * Wp, D), 'attn')
-        x = x + F.linear(y, wq(sd[p + 'attn.proj.weight']), sd[p + 'attn.proj.bias'])
+        x = x + F.linear(y, wq(sd[p + 'attn.proj.weight'], 'proj'), sd[p + 'attn.proj.bias'])
         y = aq(F.layer_norm(x, (D,), sd[p + 'norm2.weight'], sd[p + 'norm2.bias'], eps=1e-6), 'ln2')
-        y = aq(F.gelu(F.linear(y, wq(sd[p + 'mlp.fc1.weight']), sd[p + 'mlp.fc1.bias'])), 'hid')
-        x = x + F.linear(y, wq(sd[p + 'mlp.fc2.weight']), sd[p + 'mlp.fc2.bias'])
+        y = aq(F.gelu(F.linear(y, wq(sd[p + 'mlp.fc1.weight'], 'fc1'), sd[p + 'mlp.fc1.bias'])), 'hid')
+        x = x + F.linear(y, wq(sd[p + 'mlp.fc2.weight'], 'fc2'), sd[p + 'mlp.fc2.bias'])
     x = r(F.layer_norm(x, (D,), sd['backbone.last_norm.weight'], sd['backbone.last_norm.bias'], eps=1e-6))
     x = x.permute(0, 2, 1).reshape(B, D, 16, 12)
     h = 'keypoint_head.deconv_layers.'
@@ -100,8 +119,34 @@ def main():
     ap.add_argument('--crops', type=int, default=4)
     ap.add_argument('--variant', default='b')
     ap.add_argument('--dataset', default='ap10k')
+    ap.add_argument('--families', action='store_true', help='MXFP8 on ONE GEMM family at a time, on the first --crops crops of the configuration\'s full-batch golden '
+                    'workload (peaked checkpoint): which family alone keeps the confidences within 1e-3?')
     args = ap.parse_args()
     torch.set_num_threads(16)
+    if args.families:
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden'))
+        from cases import fullbatch_crops, fullbatch_plan
+        n_full = {(v, d): n for v, d, n in fullbatch_plan()}[(args.variant, args.dataset)]
+        with torch.no_grad():
+            shp = model_shape(args.variant, args.dataset)
+            sd = O.to_torch_state_dict(synthetic_state_dict(shp, 0, peaked=True))
+            crops = fullbatch_crops(n_full)[:args.crops]
+            x = torch.from_numpy(np.concatenate([O.pre_img(c)[0] for c in crops]))
+            def run(mode, fams=None):
+                return np.concatenate([fwd(sd, x[i:i + 4], shp.depth, shp.num_heads, mode, families=fams).numpy() for i in range(0, len(x), 4)])
+            ref = run('fp32')
+            ref_kp = O.decode_per_crop(ref)
+            print(f'# ViTPose-{args.variant.upper()} / {args.dataset}: first {len(x)} crops of the {n_full}-crop golden workload, peaked checkpoint, {ref_kp[..., 2].size} joints; errors against the fp32 oracle')
+            print(f'{"operands":34s} {"conf max":>10s} {"conf rms":>10s} {"joints > 1e-3":>14s} {"coord max px":>13s}')
+            rows = [('fp16 everywhere (shipped default)', 'fp16', None)] + [(f'MXFP8 {f} only', 'mx', [f]) for f in ('qkv', 'proj', 'fc1', 'fc2')] + \
+                   [('MXFP8 fc1 + fc2', 'mx', ['fc1', 'fc2']), ('MXFP8 qkv + proj', 'mx', ['qkv', 'proj']), ('MXFP8 all four (the fp8 mode)', 'mx', None),
+                    ('e4m3 WEIGHTS only, all four', 'w8', None)]
+            for name, mode, fams in rows:
+                kp = O.decode_per_crop(run(mode, fams))
+                dc = np.abs(kp[..., 2] - ref_kp[..., 2])
+                dp = np.abs(kp[..., :2] - ref_kp[..., :2]).max(-1)
+                print(f'{name:34s} {dc.max():10.3e} {np.sqrt((dc ** 2).mean()):10.3e} {int((dc > 1e-3).sum()):8d} / {dc.size:<4d} {dp.max():13.3f}', flush=True)
+        return
     with torch.no_grad():
         shp = model_shape(args.variant, args.dataset)
         crops = np.concatenate([synthetic_crops(args.crops // 2, 21, 'blobs'), synthetic_crops(args.crops - args.crops // 2, 22, 'noise')])
