@@ -668,6 +668,8 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs g) {
                     }
                 }
             };
+            // (a static issue priority for either wave group inside this epilogue -- s_setprio 2 for waves 4-7 or for waves 0-3 -- measured no change:
+            // fc1 2.745 / 2.772 / 2.741 ms per step, profiles/gemm8_timeline_r5.txt)
             if (g.rowstat != nullptr) epilogue(std::true_type{});
             else epilogue(std::false_type{});
             if (tl && lane == 0 && (wave & 3) == 0) {   // stamps of waves 0 and 4 (one per stagger group): [wg][group][tile < 16][8]
