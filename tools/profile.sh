@@ -10,12 +10,12 @@ OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 BENCH="python $ROOT/bench.py --no-cpu-baseline --no-host-path --no-clock --steps 5 --warmup 2 $*"
-rocprofv3 --kernel-trace --stats -d $OUT/stats -o trace -- $BENCH > $OUT/stats.log 2>&1
+timeout 240 rocprofv3 --kernel-trace --stats -d $OUT/stats -o trace -- $BENCH > $OUT/stats.log 2>&1
 PMCB="python $ROOT/bench.py --no-cpu-baseline --no-host-path --no-clock --steps 1 --warmup 1 $*"
-rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -d $OUT/pmc_sq -o pmc -- $PMCB > $OUT/pmc_sq.log 2>&1
-rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum GRBM_GUI_ACTIVE -d $OUT/pmc_tcc -o pmc -- $PMCB > $OUT/pmc_tcc.log 2>&1
-rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_fetch -o pmc -- $PMCB > $OUT/pmc_fetch.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc_write -o pmc -- $PMCB > $OUT/pmc_write.log 2>&1
+timeout 240 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -d $OUT/pmc_sq -o pmc -- $PMCB > $OUT/pmc_sq.log 2>&1
+timeout 240 rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum GRBM_GUI_ACTIVE -d $OUT/pmc_tcc -o pmc -- $PMCB > $OUT/pmc_tcc.log 2>&1
+timeout 240 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_fetch -o pmc -- $PMCB > $OUT/pmc_fetch.log 2>&1
+timeout 240 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc_write -o pmc -- $PMCB > $OUT/pmc_write.log 2>&1
 # keep only the small CSVs
 find $OUT -name "*.csv" -size +20M -delete
 ls -R $OUT | head -50
