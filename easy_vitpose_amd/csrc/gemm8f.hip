@@ -173,6 +173,7 @@ __global__ __launch_bounds__(512, 2) void gemm8f_kernel(GemmArgs g) {
         __builtin_amdgcn_sched_barrier(0);
         issue(1, B ^ 1, kA, sx1[B ^ 1]);
         if constexpr (MODE != 1) wait_vm<NKEEP>();
+        asm volatile("" : "+v"(sx1[B]));     // retired by the wait above: re-defined HERE for the compiler, so that no copy or use of it can move in front of the wait
         wait_lgkm<0>();
         bar();
         __builtin_amdgcn_s_setprio(1);
@@ -189,6 +190,7 @@ __global__ __launch_bounds__(512, 2) void gemm8f_kernel(GemmArgs g) {
         issue(0, B, kB, sx0[B]);
         issue(3, B, kB, dummy);
         if constexpr (MODE == 2) wait_vm<NLB>(); else wait_vm<NKEEP>();
+        asm volatile("" : "+v"(sx0[B ^ 1]));   // retired by the wait above (read by the next K-tile's first MFMA section)
         wait_lgkm<0>();
         bar();
         __builtin_amdgcn_s_setprio(1);
@@ -231,6 +233,10 @@ __global__ __launch_bounds__(512, 2) void gemm8f_kernel(GemmArgs g) {
         ktile(B1{}, M2{}, 0, 1, false, 0, 0);
 
         // ---------------- epilogue of tile (m0, n0) ----------------
+        // the MFMAs are inline asm: hipcc's hazard recognizer does not know that the accumulators were written by the matrix pipe.  The last MFMA section is
+        // followed by a barrier and the epilogue's own address arithmetic, but the wait states an MFMA result needs before a VALU read (<= 18) are spent
+        // HERE explicitly, once per tile, so that no compiler version can schedule the first read too early
+        asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
         int frow_e = frow, fg_e = fg;
         asm volatile("" : "+v"(frow_e), "+v"(fg_e));
         if constexpr (!RESID_LDS) { if (!wr) bar(); }

@@ -221,7 +221,7 @@ def test_fused_qkv_attention_is_bit_identical(monkeypatch, variant, dataset, dty
     assert np.array_equal(odd, ref_kp[:n - 1])
 
 
-@pytest.mark.parametrize('dtype,n', [('fp16', 32), ('fp16', 17), ('bf16', 16)])
+@pytest.mark.parametrize('dtype,n', [('fp16', 32), ('fp16', 17), ('fp16', 13), ('bf16', 16)])   # 13 crops: 208 tiles = 208 workgroups, a grid that is no multiple of 8
 def test_fused_qkv_attention_head_dim_80_is_bit_identical(monkeypatch, dtype, n):
     """ViTPose-H (head dim 80, BASELINE configs[2]'s model): attn.qkv + the attention core as ONE kernel per (crop, head) -- gemm8.hip's 192 x 256 tile with
     EPI_QKV_ATTN: [q_h | k_h | v_h | 16 zero rows] head-major weights, q / k / v handed over through LDS, 12 query tiles on 8 waves -- against the two-launch
