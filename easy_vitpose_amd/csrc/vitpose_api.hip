@@ -666,7 +666,11 @@ int forward_chunk(vp_ctx* c, const void* d_crops, int fmt, int n, bool want_toke
             vp::GemmArgs g80{};
             if (b.w_qkvh && c->heads * 80 == D) {
                 g80.A = xh; g80.W = b.w_qkvh; g80.bias = b.b_qkvh; g80.ln_s = b.s_qkvh; g80.rowstat = c->rowstat; g80.out = c->y;
-                g80.M = M; g80.N = c->heads * 256; g80.K = D; g80.ldo = D; g80.w_rows = c->heads * 256; g80.variant = 18; g80.group_m = 0;
+                g80.M = M; g80.N = c->heads * 256; g80.K = D; g80.ldo = D; g80.w_rows = c->heads * 256; g80.variant = 18;
+                // tile order: groups of 8 crops x all heads, crop fastest -- the 32 workgroups of an XCD then work on 8 crops x 4 heads at a time (12 operand K-slices
+                // fetched per K-tile for 32 tiles instead of 18 with the head-fastest order: PMC traffic 800 -> ~450 MB per launch, profiles/qkvattn80_r5.txt)
+                static const int qa80_group = [] { const char* e = getenv("VP_QA80_GROUP"); return e ? atoi(e) : 8; }();
+                g80.group_m = qa80_group;
                 g80.attn_scale_log2e = (1.0f / sqrtf(80.0f)) * 1.4426950408889634f;
                 g80.ablate = c->gemm_ablate | c->fam_ablate[VP_PROF_GEMM_QKV];
             }
