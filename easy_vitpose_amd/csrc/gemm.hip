@@ -383,8 +383,14 @@ __global__ __launch_bounds__(C::NT, 2) void gemm_kernel(GemmArgs g) {
             asm volatile("" ::: "memory");
         }
     } else {
+    // PIPE 6 (round 5, small batches): TWO k-blocks per barrier.  A 64 x 64 tile spends ~500 of the ~760 cycles of a k-step on the wait, the barrier and the
+    // LDS round trip in front of its 8 MFMAs per wave, and at a few crops no second workgroup shares the SIMD to hide them; with two k-blocks per barrier that
+    // overhead is paid once per 128 k.  Same k order, same MFMAs: bit-identical.  Ring: tile j in slot j % STAGES; the prologue issues STAGES - KS tiles, an
+    // iteration issues the KS tiles that go into the slots the previous iteration read.
+    constexpr int KS = (C::PIPE == 6) ? 2 : 1;
+    static_assert(C::PIPE != 6 || (C::STAGES >= 4 && C::KK == 2), "PIPE 6: >= 4 stages, BK = 64");
 #pragma unroll
-    for (int s = 0; s < C::STAGES - 1; ++s)
+    for (int s = 0; s < C::STAGES - KS; ++s)
         if (s < nk) stage(s, s);
     if constexpr (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) {
         // Fused LayerNorm at small batch (GemmArgs::ln_part): the tile's BM rows are merged ONCE, one row per thread, and shared through LDS
@@ -409,15 +415,22 @@ __global__ __launch_bounds__(C::NT, 2) void gemm_kernel(GemmArgs g) {
             }
         }
     }
-    int buf = 0, pbuf = C::STAGES - 1;
-    for (int kt = 0; kt < nk; ++kt) {
-        // tile kt has landed once at most STAGES-2 younger tiles are still in flight
-        if (C::STAGES > 2 && kt + C::STAGES - 2 < nk) wait_vmcnt<C::G * (C::STAGES - 2)>();
+    int buf = 0, pbuf = C::STAGES - KS;
+    for (int kt = 0; kt < nk; kt += KS) {   // PIPE 6: nk is even (launch() checks K % 128 == 0)
+        // tiles kt .. kt+KS-1 have landed once at most STAGES-2 KS younger tiles are still in flight (all of them issued: kt + STAGES - KS <= nk)
+        if (C::STAGES > 2 * KS && kt + C::STAGES - KS <= nk) wait_vmcnt<C::G * (C::STAGES - 2 * KS)>();
         else wait_vmcnt<0>();
-        __builtin_amdgcn_s_barrier();   // every wave's share of tile kt landed; everyone finished tile kt-1
+        __builtin_amdgcn_s_barrier();   // every wave's share of tiles kt .. kt+KS-1 landed; everyone finished tiles kt-KS .. kt-1
         asm volatile("" ::: "memory");
-        if (kt + C::STAGES - 1 < nk && !(VP_ABLATE(g) & 1)) stage(kt + C::STAGES - 1, pbuf);
-        const char* sb = smem + buf * C::STAGE_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int pb = pbuf + ks >= C::STAGES ? pbuf + ks - C::STAGES : pbuf + ks;
+            if (kt + C::STAGES - KS + ks < nk && !(VP_ABLATE(g) & 1)) stage(kt + C::STAGES - KS + ks, pb);
+        }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+        const int cbuf = buf + ks >= C::STAGES ? buf + ks - C::STAGES : buf + ks;
+        const char* sb = smem + cbuf * C::STAGE_BYTES;
         if constexpr (C::PIPE == 5) {
             // reads: per k-half wf[0..TI-1] then af[0..TJ-1] (R = TI + TJ); k-half 0 is issued up front, two
             // reads of k-half 1 after each MFMA group of k-half 0.  Group (kk, j) = TI MFMAs wf[kk][*] x af[kk][j];
@@ -426,7 +439,7 @@ __global__ __launch_bounds__(C::NT, 2) void gemm_kernel(GemmArgs g) {
             static_assert(C::KK == 2 && C::TI + C::TJ <= 12 && 2 * C::TJ >= C::TI + C::TJ, "PIPE 5 schedule");
             constexpr int R = C::TI + C::TJ;
             u32x4 f0[R], f1[R];                       // [0, TI): weight fragments, [TI, R): activation fragments
-            const uint32_t lb = (uint32_t)(size_t)(lds_ptr_t)(smem) + buf * C::STAGE_BYTES;
+            const uint32_t lb = (uint32_t)(size_t)(lds_ptr_t)(smem) + cbuf * C::STAGE_BYTES;
             const uint32_t wa0 = lb + woff, wa1 = lb + (woff ^ 64), aa0 = lb + aoff, aa1 = lb + (aoff ^ 64);
             lds_read_frags<C::ROWB>(f0, wa0, std::make_integer_sequence<int, C::TI>{});
             lds_read_frags<C::ROWB>(f0 + C::TI, aa0, std::make_integer_sequence<int, C::TJ>{});
@@ -435,7 +448,7 @@ __global__ __launch_bounds__(C::NT, 2) void gemm_kernel(GemmArgs g) {
             pipe5_half0<T, C, 0>(acc, f0, f1, wa1, aa1);
             pipe5_half1<T, C, 0>(acc, f1);
             __builtin_amdgcn_s_setprio(0);
-        } else if (C::PIPE && C::KK == 2) {
+        } else if (C::PIPE == 1 && C::KK == 2) {
             // software pipelined fragment reads: the ds_reads of k-half 1 are issued between the two MFMA
             // blocks of k-half 0 and complete in their shadow (lgkmcnt is only 4 bits wide, so no more than
             // one half's reads are outstanding at a wait); sched_barriers pin this order for the compiler.
@@ -480,8 +493,9 @@ __global__ __launch_bounds__(C::NT, 2) void gemm_kernel(GemmArgs g) {
                     for (int j = 0; j < C::TJ; ++j) acc[i][j] = mfma16<T>(wf[i], af[j], acc[i][j]);
             }
         }
-        buf = (buf + 1 == C::STAGES) ? 0 : buf + 1;
-        pbuf = (pbuf + 1 == C::STAGES) ? 0 : pbuf + 1;
+        }
+        buf = (buf + KS >= C::STAGES) ? buf + KS - C::STAGES : buf + KS;
+        pbuf = (pbuf + KS >= C::STAGES) ? pbuf + KS - C::STAGES : pbuf + KS;
     }
 
     }
@@ -1195,6 +1209,23 @@ using Cfg13 = TileCfg<128, 128, 64, 64, 64, 3, 1, 0>;   //  96 KiB   4   (1 bloc
 using Cfg14 = TileCfg<64, 64, 64, 32, 32, 3, 0, 0>;     //  48 KiB   4   (3 blocks / CU)  Cfg9 with a 3-stage ring
 using Cfg15 = TileCfg<128, 64, 64, 64, 32, 3, 0, 0>;    //  72 KiB   4   (2 blocks / CU)  128(m) x 64(n), 3-stage ring
 static constexpr int NUM_TILE_CFGS = 16;
+// (16-18 = the 8-phase kernel of gemm8.hip.)  Round 5, small batches IN SITU: every layer's weights are first touched from HBM (ViTPose-L: 25 MB per layer,
+// 600 MB per forward -- more than L2 + the memory-side cache hold), so a k-block costs an HBM round trip, not the L2 hit the isolated sweeps of rounds 2-3 saw:
+// a workgroup retires STAGES - 1 k-blocks per round trip whatever its tile, and one full round of workgroups with a deep ring beats more, smaller tiles.
+using Cfg19 = TileCfg<192, 128, 64, 96, 64, 3, 1, 0>;   // 120 KiB   4   (1 block / CU)   Cfg8 with a 3-stage ring
+using Cfg20 = TileCfg<192, 128, 64, 48, 64, 3, 1, 0>;   // 120 KiB   8   (1 block / CU)   Cfg11 with a 3-stage ring
+using Cfg21 = TileCfg<64, 64, 64, 32, 32, 5, 0, 0>;     //  80 KiB   4   (2 blocks / CU)  Cfg9 with a 5-stage ring
+using Cfg22 = TileCfg<128, 64, 64, 64, 32, 6, 0, 0>;    // 144 KiB   4   (1 block / CU)   128(m) x 64(n), 6-stage ring
+using Cfg23 = TileCfg<64, 64, 64, 32, 32, 8, 0, 0>;     // 128 KiB   4   (1 block / CU)   Cfg9 with an 8-stage ring
+using Cfg24 = TileCfg<128, 128, 64, 64, 64, 4, 1, 0>;   // 128 KiB   4   (1 block / CU)   Cfg1 with a 4-stage ring
+using Cfg25 = TileCfg<128, 128, 32, 64, 64, 4, 0, 0>;   //  64 KiB   4   (2 blocks / CU)  128 x 128 with k-blocks of 32: 4-stage ring in Cfg1's LDS
+using Cfg26 = TileCfg<128, 128, 32, 64, 64, 5, 0, 0>;   //  80 KiB   4   (2 blocks / CU)  ... 5-stage
+using Cfg27 = TileCfg<64, 64, 64, 32, 32, 4, 1, 0>;     //  64 KiB   4   (2 blocks / CU)  Cfg12 with pipelined fragment reads
+using Cfg28 = TileCfg<64, 64, 64, 32, 32, 5, 6, 0>;     //  80 KiB   4   (2 blocks / CU)  64 x 64, two k-blocks per barrier, 5-stage ring (3 k-blocks in flight)
+using Cfg29 = TileCfg<64, 64, 64, 32, 32, 4, 6, 0>;     //  64 KiB   4   (2 blocks / CU)  ... 4-stage ring (2 in flight)
+using Cfg30 = TileCfg<64, 64, 64, 32, 32, 6, 6, 0>;     //  96 KiB   4   (1 block / CU)   ... 6-stage ring (4 in flight)
+using Cfg31 = TileCfg<32, 64, 64, 16, 32, 6, 6, 0>;     //  72 KiB   4   (2 blocks / CU)  32(m) x 64(n): twice the workgroups of a 1-2 crop GEMM, half the MFMAs per wave and k-block
+using Cfg32 = TileCfg<32, 64, 64, 16, 32, 8, 6, 0>;     //  96 KiB   4   (1 block / CU)   ... 8-stage ring (6 in flight)
 
 template <class T, int EPI, int AMODE, class C>
 static hipError_t launch(const GemmArgs& a, hipStream_t s) {
@@ -1205,6 +1236,7 @@ static hipError_t launch(const GemmArgs& a, hipStream_t s) {
     constexpr int LN_STAT_BYTES = C::BM * 8;   // (mean, rstd) per tile row behind the ring: used when GemmArgs::ln_part is set
     static_assert(LDS_BYTES + LN_STAT_BYTES <= 160 * 1024, "LDS");
     if (a.ln_part && (C::PIPE == 2 || C::PIPE == 3 || C::DIRECT)) return hipErrorInvalidValue;   // the prologue merge lives in the generic loop
+    if (C::PIPE == 6 && a.K % 128 != 0) return hipErrorInvalidValue;                                      // two k-blocks per barrier
     if (a.ln_part && C::BM * a.ln_tiles * 8 > C::STAGE_BYTES) return hipErrorInvalidValue;                  // ... and borrows one ring slot
     if (a.ln_part && (a.ln_tiles & 1)) return hipErrorInvalidValue;   // the block of partial statistics is DMA'd in 16-byte pieces: rows of ln_tiles * 8 bytes must be 16-byte multiples
     static bool attr_done[64] = {};   // the > 64 KiB LDS opt-in is a per-device function attribute
@@ -1228,7 +1260,7 @@ static hipError_t launch(const GemmArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
-// the product library carries the configurations the selection rule of vitpose_api.hip gemm() can pick (1, 3, 8, 9, 11, 12);
+// the product library carries the configurations the selection rule of vitpose_api.hip gemm() can pick (1, 3, 8, 9, 11, 12, 30, 31);
 // the measured alternatives are instantiated in the VP_TOOLS build only
 #ifdef VP_TOOLS
 #define VP_TOOLS_CASE(v) case v: return launch<T, EPI, AMODE, Cfg##v>(a, s);
@@ -1254,6 +1286,20 @@ static hipError_t by_variant(const GemmArgs& a, hipStream_t s) {
         VP_TOOLS_CASE(13)
         VP_TOOLS_CASE(14)
         VP_TOOLS_CASE(15)
+        VP_TOOLS_CASE(19)
+        VP_TOOLS_CASE(20)
+        VP_TOOLS_CASE(21)
+        VP_TOOLS_CASE(22)
+        VP_TOOLS_CASE(23)
+        VP_TOOLS_CASE(24)
+        VP_TOOLS_CASE(25)
+        VP_TOOLS_CASE(26)
+        VP_TOOLS_CASE(27)
+        VP_TOOLS_CASE(28)
+        VP_TOOLS_CASE(29)
+        case 30: return launch<T, EPI, AMODE, Cfg30>(a, s);
+        case 31: return launch<T, EPI, AMODE, Cfg31>(a, s);
+        VP_TOOLS_CASE(32)
     }
     return hipErrorInvalidValue;
 }
@@ -1281,6 +1327,8 @@ int gemm_tile_bn(int variant) {
                                           Cfg12::BN, Cfg13::BN, Cfg14::BN, Cfg15::BN};
     if (variant == 16 || variant == 18) return 256;
     if (variant == 17) return 192;
+    if (variant == 19 || variant == 20 || (variant >= 24 && variant <= 26)) return 128;
+    if ((variant >= 21 && variant <= 23) || (variant >= 27 && variant <= 32)) return 64;
     return (variant >= 0 && variant < NUM_TILE_CFGS) ? bn[variant] : 0;
 }
 

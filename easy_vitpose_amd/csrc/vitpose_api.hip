@@ -479,8 +479,23 @@ int gemm(vp_ctx* c, int fam, int epi, const uint16_t* A, const uint16_t* W, cons
         const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128) * par_;
         if (t192 < 384) {
             g.variant = (t128 >= 256) ? 1 : 9; g.group_m = 0;
-            // long-K GEMMs on 64 x 64 tiles (fc2 of a few crops) are bound by the latency of every k-block: 4-stage ring (tools/gemm_small.py: -20 %)
-            if (g.variant == 9 && K >= 2048) g.variant = 12;
+            // 64 x 64 tiles are bound by the latency of every k-block (a workgroup retires STAGES - 1 k-blocks per round trip) and, with one workgroup per SIMD set,
+            // by the ~500 cycles of wait + barrier + LDS round trip in front of the 8 MFMAs of a k-step.  Inside the step every layer's weights are first touched
+            // from HBM, so the round trip is ~2 x what the isolated sweeps of rounds 2-3 (weights L2-resident) saw.  Round 5, measured IN SITU
+            // (tools/small_sweep.py, profiles/small_batch_r5.txt), every choice with the same k order = bit-identical:
+            //   * <= 512 tiles (all resident at the 2 workgroups per CU of the 4-stage ring), or long K (round 2): Cfg12;
+            //   * <= 256 tiles: Cfg30 = 6-stage ring, TWO k-blocks per barrier (gemm.hip PIPE 6), one workgroup per CU;
+            //   * <= 256 tiles of 32 x 64: Cfg31 = that schedule on 32(m) x 64(n) tiles -- twice the workgroups, half the MFMAs per wave and k-block.
+            // attn.proj of 1-8 crops 17-20 -> 10-13 us, mlp.fc2 of one crop 24.5 -> 17-21.5 us, qkv / fc1 of one crop 18 -> 12 us; ViTPose-L 1 crop 1.90 -> ~1.4 ms,
+            // 8 crops 2.50 -> 2.35 ms; -B 1 crop 0.73 -> ~0.59 ms; -H 1 crop 3.00 -> ~2.3 ms.  More tiles than 512 would run the deep rings in two rounds and lose
+            // against the 5 workgroups per CU of the 2-stage ring.
+            const long t64 = (long)((M + 63) / 64) * ((N + 63) / 64) * par_;
+            const long t32 = (long)((M + 31) / 32) * ((N + 63) / 64) * par_;
+            if (g.variant == 9) {
+                if (K % 128 == 0 && t32 <= 256) g.variant = 31;
+                else if (K % 128 == 0 && t64 <= 256) g.variant = 30;
+                else if (K >= 2048 || t64 <= 512) g.variant = 12;
+            }
         }
     }
     if (c->persist_gemm && g.variant == 8 && (epi == vp::EPI_BIAS || epi == vp::EPI_BIAS_GELU) && K % 128 == 0 && ldo == N &&
@@ -522,7 +537,7 @@ int gemm(vp_ctx* c, int fam, int epi, const uint16_t* A, const uint16_t* W, cons
     }
     if (g.ln_part) {   // only the one-tile-per-workgroup 2-phase kernel folds partial statistics itself
         g.persist = 0;
-        if (g.variant >= 16) { g.variant = 8; g.group_m = 8; }
+        if (g.variant >= 16 && g.variant <= 18) { g.variant = 8; g.group_m = 8; }
     }
     const bool deconv = epi == vp::EPI_DECONV || epi == vp::EPI_DECONV_FINAL;
     const double par = deconv ? 4.0 : 1.0;

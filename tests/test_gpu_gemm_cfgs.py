@@ -65,7 +65,8 @@ def test_wide_gemm_configurations(operands, name, N, epi, flags):
         ref = _gelu(ref)
     outs = {}
     for label, variant, fl in [('cfg9', 9, 0), ('cfg1', 1, 0), ('cfg8', 8, 0), ('cfg8 persistent', 8, PERS), ('cfg11', 11, 0),
-                               ('gemm8 256x256', 16, 0), ('gemm8 192x256', 18, 0), ('cfg8 reversed', 8, REV)]:
+                               ('gemm8 256x256', 16, 0), ('gemm8 192x256', 18, 0), ('cfg8 reversed', 8, REV),
+                               ('cfg12 4-stage ring', 12, 0), ('cfg30 two k-blocks per barrier', 30, 0), ('cfg31 32x64 tiles', 31, 0)]:
         outs[label] = _case(epi, variant, flags | fl, A, W, bias, rowstat=rowstat, ln_s=ln_s)
         _check16(outs[label], ref, f'{name} {label}')
     base = outs['cfg9']
@@ -99,7 +100,8 @@ def test_residual_gemm_configurations(operands, name, K, flags):
     x0 = hi.astype(np.float64) + round_to(resid - hi, 'fp16').astype(np.float64)          # what the two planes hold
     ref = A.astype(np.float64) @ W.astype(np.float64).T + bias + x0
     outs = {}
-    for label, variant in [('cfg11', 11), ('cfg8', 8), ('cfg9', 9), ('gemm8 256x192', 17), ('gemm8 256x256', 16), ('gemm8 192x256', 18)]:
+    for label, variant in [('cfg11', 11), ('cfg8', 8), ('cfg9', 9), ('gemm8 256x192', 17), ('gemm8 256x256', 16), ('gemm8 192x256', 18),
+                           ('cfg12 4-stage ring', 12), ('cfg30 two k-blocks per barrier', 30), ('cfg31 32x64 tiles', 31)]:
         o, st = _case(6, variant, flags, A, W, bias, aux=resid, want_stats=True, group_m=0 if variant < 16 else 8)
         outs[label] = (o, st)
         assert np.abs(o - ref).max() < 2e-5 * max(1.0, np.abs(ref).max()), f'{name} {label}: planes off by {np.abs(o - ref).max():.3e}'
@@ -143,11 +145,15 @@ def test_patch_embed_epilogue_with_statistics(operands):
     pos = (rng.standard_normal((192, D)) * 0.5).astype(np.float32)
     bias = np.zeros(D, np.float32)
     ref = A.astype(np.float64) @ W.astype(np.float64).T + np.tile(pos.astype(np.float64), (M // 192, 1))
-    for variant in (8, 11, 9):
+    first = None
+    for variant in (8, 11, 9, 12, 30, 31):
         o, st = _case(7, variant, 0, A, W, bias, aux=pos, want_stats=True, group_m=0)
         assert np.abs(o - ref).max() < 2e-5 * max(1.0, np.abs(ref).max())
         g = o.astype(np.float64).reshape(M, D // 64, 64)
         assert np.abs(st[..., 0] - g.sum(-1)).max() < 2e-3
+        if first is None:
+            first = (o, st)
+        assert np.array_equal(o, first[0]) and np.array_equal(st, first[1]), f'patch embed: cfg{variant} differs from cfg8'
 
 
 @pytest.mark.parametrize('kp', [17, 133])
@@ -159,6 +165,6 @@ def test_final_conv_hi_lo_weights(kp):
     W = (rng.standard_normal((kp, 256)) * 0.02).astype(np.float32)
     bias = (rng.standard_normal(kp) * 0.02).astype(np.float32)
     ref = (A.astype(np.float64) @ W.astype(np.float64).T + bias).reshape(B, 3072, kp).transpose(0, 2, 1)
-    for variant in (8, 1, 9):
+    for variant in (8, 1, 9, 12, 30, 31):
         o = _case(5, variant, 0, A, W, bias, group_m=0, out_shape=(B, kp, 3072))
         assert np.abs(o - ref).max() < 3e-6 * max(1.0, np.abs(ref).max()), f'heatmap cfg{variant}: {np.abs(o - ref).max():.3e}'
