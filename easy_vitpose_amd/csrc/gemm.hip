@@ -1260,7 +1260,7 @@ static hipError_t launch(const GemmArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
-// the product library carries the configurations the selection rule of vitpose_api.hip gemm() can pick (1, 3, 8, 9, 11, 12, 30, 31);
+// the product library carries the configurations the selection rule of vitpose_api.hip gemm() can pick (1, 3, 8, 9, 11, 12, 15, 30, 31);
 // the measured alternatives are instantiated in the VP_TOOLS build only
 #ifdef VP_TOOLS
 #define VP_TOOLS_CASE(v) case v: return launch<T, EPI, AMODE, Cfg##v>(a, s);
@@ -1285,7 +1285,7 @@ static hipError_t by_variant(const GemmArgs& a, hipStream_t s) {
         case 12: return launch<T, EPI, AMODE, Cfg12>(a, s);
         VP_TOOLS_CASE(13)
         VP_TOOLS_CASE(14)
-        VP_TOOLS_CASE(15)
+        case 15: return launch<T, EPI, AMODE, Cfg15>(a, s);
         VP_TOOLS_CASE(19)
         VP_TOOLS_CASE(20)
         VP_TOOLS_CASE(21)

@@ -489,12 +489,19 @@ int gemm(vp_ctx* c, int fam, int epi, const uint16_t* A, const uint16_t* W, cons
             // attn.proj of 1-8 crops 17-20 -> 10-13 us, mlp.fc2 of one crop 24.5 -> 17-21.5 us, qkv / fc1 of one crop 18 -> 12 us; ViTPose-L 1 crop 1.90 -> ~1.4 ms,
             // 8 crops 2.50 -> 2.35 ms; -B 1 crop 0.73 -> ~0.59 ms; -H 1 crop 3.00 -> ~2.3 ms.  More tiles than 512 would run the deep rings in two rounds and lose
             // against the 5 workgroups per CU of the 2-stage ring.
+            //   * residual GEMMs (attn.proj, mlp.fc2) with MORE than 512 tiles of 64 x 64 but <= 512 of 128(m) x 64(n) (12-28 crops): Cfg15 = that tile on a 3-stage
+            //     ring, all resident at 2 workgroups per CU -- the 4-stage 64 x 64 ring ran them in two rounds: fc2 of 16 crops 42 -> 34 us (-B), 56.5 -> 44 (-L),
+            //     of 12 crops 72 -> 54 (-H); ViTPose-L 12 / 16 crops 3.40 -> 3.09 / 3.62 -> 3.32 ms, -B 16 / 24 crops 1.48 -> 1.36 / 1.71 -> 1.56 ms.  For the wide
+            //     GEMMs the same tile is neutral (measured), so they keep the 2-stage 64 x 64 ring there.
             const long t64 = (long)((M + 63) / 64) * ((N + 63) / 64) * par_;
             const long t32 = (long)((M + 31) / 32) * ((N + 63) / 64) * par_;
+            const long t128x64 = (long)((M + 127) / 128) * ((N + 63) / 64) * par_;
             if (g.variant == 9) {
                 if (K % 128 == 0 && t32 <= 256) g.variant = 31;
                 else if (K % 128 == 0 && t64 <= 256) g.variant = 30;
-                else if (K >= 2048 || t64 <= 512) g.variant = 12;
+                else if (t64 <= 512) g.variant = 12;
+                else if (epi == vp::EPI_BIAS_RESID_LN && t128x64 <= 512) g.variant = 15;
+                else if (K >= 2048) g.variant = 12;
             }
         }
     }

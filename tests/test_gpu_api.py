@@ -328,6 +328,35 @@ def test_every_tile_choice_of_the_selection_rule_is_bit_identical():
     assert {v for p in seen for v in p} >= {0, 16, 17, 18}
 
 
+_C31, _C30, _C12, _C15 = '<32, 64, 64, 16, 32, 6, 6', '<64, 64, 64, 32, 32, 6, 6', '<64, 64, 64, 32, 32, 4, 0', '<128, 64, 64, 64, 32, 3, 0'
+
+
+@pytest.mark.parametrize('variant,dataset,cases', [
+    ('b', 'coco', [(1, _C31, _C31), (4, _C30, _C30), (12, _C12, _C12), (16, _C15, _C15), (24, _C15, _C15)]),
+    ('l', 'coco_25', [(2, _C31, _C31), (12, _C15, _C15)]),
+    ('s', 'coco', [(3, _C31, _C31)]),
+])
+def test_small_batch_tile_rule_is_bit_identical(variant, dataset, cases):
+    """Round 5: below the 8-phase regime the residual GEMMs run on 32 x 64 / 64 x 64 tiles with TWO k-blocks per barrier (<= 256 tiles), on the 4-stage 64 x 64 ring
+    (<= 512 tiles) or on the 3-stage 128 x 64 tile (12-28 crops) -- vitpose_api.hip gemm().  Same k order: every crop must equal the max_batch = 8 path bit for bit
+    (whose own GEMMs are 128 x 128 / 4-stage 64 x 64 tiles), and the kernels must be the ones the rule names."""
+    shp, sd, _ = weights(variant, dataset)
+    nmax = max(n for n, _, _ in cases)
+    crops = synthetic_crops(nmax, 91, 'blobs')
+    crops[1::2] = synthetic_crops(len(crops[1::2]), 92, 'noise')
+    small = VitPoseHip(shp, sd, dtype='fp16', max_batch=8)
+    ref = small.infer(crops) if nmax > 8 else small.infer(np.concatenate([crops, synthetic_crops(8 - nmax, 93, 'noise')]))[:nmax]
+    small.close()
+    for n, proj, fc2 in cases:
+        eng = VitPoseHip(shp, sd, dtype='fp16', max_batch=n)
+        out = eng.infer(crops[:n])
+        out2 = eng.infer(crops[:n])                      # second sighting of the chunk: the hipGraph replay (<= 16 crops)
+        kp, kf = eng.profile_kernel('gemm_proj'), eng.profile_kernel('gemm_fc2')
+        eng.close()
+        assert proj in kp and fc2 in kf, (n, kp, kf)
+        assert np.array_equal(out, ref[:n]) and np.array_equal(out2, ref[:n]), f'{variant} batch {n} ({kp} / {kf}): {(out != ref[:n]).any(axis=(1, 2)).sum()} crops differ'
+
+
 def test_deconv_parity_order_is_bit_identical(monkeypatch):
     """VP_DECONV_PARITY_FAST (product-side switch): the four output parities of a deconv tile as consecutive logical blocks (same XCD: shared input
     rows) against parity-major launch order -- the same tiles, the same arithmetic: heatmaps bit for bit, fused and un-fused head."""

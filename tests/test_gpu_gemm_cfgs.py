@@ -101,7 +101,7 @@ def test_residual_gemm_configurations(operands, name, K, flags):
     ref = A.astype(np.float64) @ W.astype(np.float64).T + bias + x0
     outs = {}
     for label, variant in [('cfg11', 11), ('cfg8', 8), ('cfg9', 9), ('gemm8 256x192', 17), ('gemm8 256x256', 16), ('gemm8 192x256', 18),
-                           ('cfg12 4-stage ring', 12), ('cfg30 two k-blocks per barrier', 30), ('cfg31 32x64 tiles', 31)]:
+                           ('cfg12 4-stage ring', 12), ('cfg15 128x64 tiles', 15), ('cfg30 two k-blocks per barrier', 30), ('cfg31 32x64 tiles', 31)]:
         o, st = _case(6, variant, flags, A, W, bias, aux=resid, want_stats=True, group_m=0 if variant < 16 else 8)
         outs[label] = (o, st)
         assert np.abs(o - ref).max() < 2e-5 * max(1.0, np.abs(ref).max()), f'{name} {label}: planes off by {np.abs(o - ref).max():.3e}'
