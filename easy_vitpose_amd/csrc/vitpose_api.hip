@@ -455,6 +455,48 @@ G8Pick pick_gemm8_tile(int M, int N, bool wide, int bm192_mask, long min_tiles, 
     return pk;
 }
 
+// Tile configuration of the 2-phase kernel (gemm.hip Cfg id) for one GEMM of the path -- a pure function of the epilogue and the shape: tests/test_host_logic.py
+// walks it over every batch size of every model through the host-only tap vp_dbg_gemm2_pick (slots, rounds, the PIPE-6 precondition, the measured choices).
+//
+// Default: the 192(m) x 128(n) tile -- M is always a multiple of 192 tokens (one crop per m-tile), so the tile count divides evenly over 256 CUs x 2 workgroups at
+// the BASELINE batch; best or tied for every encoder GEMM in the MI355X sweep (profiles/gemm_tune_r1.txt); residual GEMMs: the same tile as 8 waves; wide GEMMs use
+// the grouped order.  Small batches (fewer than 384 such tiles, e.g. 8 crops per GPU of a sharded frame): tiles that still give the 256 CUs a workgroup each --
+// 128 x 128 from 256 tiles on, else 64 x 64, and inside the 64 x 64 regime (round 5, measured IN SITU: tools/small_sweep.py, profiles/small_batch_r5.txt):
+//   64 x 64 tiles are bound by the latency of every k-block (a workgroup retires STAGES - 1 k-blocks per round trip) and, with one workgroup per SIMD set, by the
+//   ~500 cycles of wait + barrier + LDS round trip in front of the 8 MFMAs of a k-step.  Inside the step every layer's weights are first touched from HBM, so the round
+//   trip is ~2 x what the isolated sweeps of rounds 2-3 (weights L2-resident) saw.  Every choice keeps the k order: bit-identical.
+//   * <= 256 tiles of 32 x 64: Cfg31 = 32(m) x 64(n) tiles, 6-stage ring, TWO k-blocks per barrier (gemm.hip PIPE 6) -- twice the workgroups, half the MFMAs per wave
+//     and k-block;  <= 256 tiles of 64 x 64: Cfg30 = that schedule on 64 x 64 tiles, one workgroup per CU;
+//   * <= 512 tiles (all resident at the 2 workgroups per CU of the 4-stage ring): Cfg12; more tiles would run the deep rings in two rounds and lose against the 5
+//     workgroups per CU of the 2-stage ring (Cfg9) -- except for long K (round 2: Cfg12 from K = 2048 on);
+//   * residual GEMMs (attn.proj, mlp.fc2) with more than 512 tiles of 64 x 64 but <= 512 of 128(m) x 64(n) (12-28 crops): Cfg15 = that tile on a 3-stage ring, all
+//     resident at 2 workgroups per CU: fc2 of 16 crops 42 -> 34 us (-B), 56.5 -> 44 (-L), of 12 crops 72 -> 54 (-H).  For the wide GEMMs the same tile is neutral.
+//   attn.proj of 1-8 crops 17-20 -> 10-13 us, mlp.fc2 of one crop 24.5 -> 17-21.5 us, qkv / fc1 of one crop 18 -> 12 us; ViTPose-L 1 crop 1.90 -> 1.36 ms, 8 crops
+//   2.50 -> 2.40 ms, 16 crops 3.62 -> 3.23 ms; -B 1 crop 0.73 -> 0.56 ms, 16 crops 1.48 -> 1.33 ms; -H 1 crop 3.00 -> 2.17 ms, 12 crops 5.49 -> 4.81 ms.
+struct Tile2Pick { int variant, group_m; };
+Tile2Pick pick_gemm2_tile(int epi, int M, int N, int K) {
+    Tile2Pick tp;
+    tp.variant = (epi == vp::EPI_BIAS_RESID || epi == vp::EPI_BIAS_RESID_LN) ? 11 : 8;
+    tp.group_m = (epi == vp::EPI_BIAS || epi == vp::EPI_BIAS_GELU) ? 8 : 0;
+    const long par_ = (epi == vp::EPI_DECONV) ? 4 : 1;   // the four output parities of a deconv are four GEMMs of one launch
+    const long t192 = (long)((M + 191) / 192) * ((N + 127) / 128) * par_;
+    const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128) * par_;
+    if (t192 >= 384) return tp;
+    tp.variant = (t128 >= 256) ? 1 : 9;
+    tp.group_m = 0;
+    if (tp.variant == 9) {
+        const long t64 = (long)((M + 63) / 64) * ((N + 63) / 64) * par_;
+        const long t32 = (long)((M + 31) / 32) * ((N + 63) / 64) * par_;
+        const long t128x64 = (long)((M + 127) / 128) * ((N + 63) / 64) * par_;
+        if (K % 128 == 0 && t32 <= 256) tp.variant = 31;
+        else if (K % 128 == 0 && t64 <= 256) tp.variant = 30;
+        else if (t64 <= 512) tp.variant = 12;
+        else if (epi == vp::EPI_BIAS_RESID_LN && t128x64 <= 512) tp.variant = 15;
+        else if (K >= 2048) tp.variant = 12;
+    }
+    return tp;
+}
+
 int gemm(vp_ctx* c, int fam, int epi, const uint16_t* A, const uint16_t* W, const float* bias, void* out,
          const float* aux, int M, int N, int K, int ldo, int Hin = 0, int Win = 0, int Cin = 0, const LnFuse* ln = nullptr) {
     vp::GemmArgs g{};
@@ -467,43 +509,8 @@ int gemm(vp_ctx* c, int fam, int epi, const uint16_t* A, const uint16_t* W, cons
     g.ablate = c->gemm_ablate | c->fam_ablate[fam];
     g.parity_fast = c->deconv_parity_fast;
     if (g.variant < 0) {
-        // default: the 192(m) x 128(n) tile -- M is always a multiple of 192 tokens (one crop per m-tile), so
-        // the tile count divides evenly over 256 CUs x 2 blocks at the BASELINE batch; best or tied for every
-        // encoder GEMM in the MI355X sweep (profiles/gemm_tune_r1.txt).  Wide-N GEMMs use the grouped order.
-        g.variant = (epi == vp::EPI_BIAS_RESID || epi == vp::EPI_BIAS_RESID_LN) ? 11 : 8;   // residual GEMMs: same tile, 8 waves
-        g.group_m = (epi == vp::EPI_BIAS || epi == vp::EPI_BIAS_GELU) ? 8 : 0;
-        // small batches (e.g. 8 crops per GPU of a sharded frame): fall back to tiles that still give the
-        // 256 CUs at least one block each
-        const long par_ = (epi == vp::EPI_DECONV) ? 4 : 1;
-        const long t192 = (long)((M + 191) / 192) * ((N + 127) / 128) * par_;
-        const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128) * par_;
-        if (t192 < 384) {
-            g.variant = (t128 >= 256) ? 1 : 9; g.group_m = 0;
-            // 64 x 64 tiles are bound by the latency of every k-block (a workgroup retires STAGES - 1 k-blocks per round trip) and, with one workgroup per SIMD set,
-            // by the ~500 cycles of wait + barrier + LDS round trip in front of the 8 MFMAs of a k-step.  Inside the step every layer's weights are first touched
-            // from HBM, so the round trip is ~2 x what the isolated sweeps of rounds 2-3 (weights L2-resident) saw.  Round 5, measured IN SITU
-            // (tools/small_sweep.py, profiles/small_batch_r5.txt), every choice with the same k order = bit-identical:
-            //   * <= 512 tiles (all resident at the 2 workgroups per CU of the 4-stage ring), or long K (round 2): Cfg12;
-            //   * <= 256 tiles: Cfg30 = 6-stage ring, TWO k-blocks per barrier (gemm.hip PIPE 6), one workgroup per CU;
-            //   * <= 256 tiles of 32 x 64: Cfg31 = that schedule on 32(m) x 64(n) tiles -- twice the workgroups, half the MFMAs per wave and k-block.
-            // attn.proj of 1-8 crops 17-20 -> 10-13 us, mlp.fc2 of one crop 24.5 -> 17-21.5 us, qkv / fc1 of one crop 18 -> 12 us; ViTPose-L 1 crop 1.90 -> ~1.4 ms,
-            // 8 crops 2.50 -> 2.35 ms; -B 1 crop 0.73 -> ~0.59 ms; -H 1 crop 3.00 -> ~2.3 ms.  More tiles than 512 would run the deep rings in two rounds and lose
-            // against the 5 workgroups per CU of the 2-stage ring.
-            //   * residual GEMMs (attn.proj, mlp.fc2) with MORE than 512 tiles of 64 x 64 but <= 512 of 128(m) x 64(n) (12-28 crops): Cfg15 = that tile on a 3-stage
-            //     ring, all resident at 2 workgroups per CU -- the 4-stage 64 x 64 ring ran them in two rounds: fc2 of 16 crops 42 -> 34 us (-B), 56.5 -> 44 (-L),
-            //     of 12 crops 72 -> 54 (-H); ViTPose-L 12 / 16 crops 3.40 -> 3.09 / 3.62 -> 3.32 ms, -B 16 / 24 crops 1.48 -> 1.36 / 1.71 -> 1.56 ms.  For the wide
-            //     GEMMs the same tile is neutral (measured), so they keep the 2-stage 64 x 64 ring there.
-            const long t64 = (long)((M + 63) / 64) * ((N + 63) / 64) * par_;
-            const long t32 = (long)((M + 31) / 32) * ((N + 63) / 64) * par_;
-            const long t128x64 = (long)((M + 127) / 128) * ((N + 63) / 64) * par_;
-            if (g.variant == 9) {
-                if (K % 128 == 0 && t32 <= 256) g.variant = 31;
-                else if (K % 128 == 0 && t64 <= 256) g.variant = 30;
-                else if (t64 <= 512) g.variant = 12;
-                else if (epi == vp::EPI_BIAS_RESID_LN && t128x64 <= 512) g.variant = 15;
-                else if (K >= 2048) g.variant = 12;
-            }
-        }
+        const Tile2Pick tp = pick_gemm2_tile(epi, M, N, K);   // the 2-phase kernels' tile (the 8-phase kernel may take the GEMM over below)
+        g.variant = tp.variant; g.group_m = tp.group_m;
     }
     if (c->persist_gemm && g.variant == 8 && (epi == vp::EPI_BIAS || epi == vp::EPI_BIAS_GELU) && K % 128 == 0 && ldo == N &&
         M % 192 == 0 && N % 128 == 0 && (long)(M / 192) * (N / 128) >= 1024)   // >= 2 tiles per resident workgroup
@@ -1396,6 +1403,15 @@ VP_API int vp_dbg_gemm8_pick(int32_t M, int32_t N, int32_t wide, int32_t bm192_m
     const G8Pick pk = pick_gemm8_tile(M, N, wide != 0, bm192_mask & 3, 448, !(bm192_mask & 4));
     if (tiles) *tiles = (int32_t)pk.tiles;
     return pk.variant;
+}
+
+// HOST ONLY: the tile configuration (gemm.hip Cfg id) the 2-phase selection rule picks for one GEMM: epi = kernels.h GemmEpi (0 bias, 1 bias + GELU, 4 deconv, 5 heatmap,
+// 6 residual + statistics, 7 pos + statistics), shape [M, N] x K; *group_m = its tile-order group
+VP_API int vp_dbg_gemm2_pick(int32_t epi, int32_t M, int32_t N, int32_t K, int32_t* group_m) {
+    if (M <= 0 || N <= 0 || K <= 0) return VP_ERR_INVALID;
+    const Tile2Pick tp = pick_gemm2_tile(epi, M, N, K);
+    if (group_m) *group_m = tp.group_m;
+    return tp.variant;
 }
 
 int vp_dbg_group_plan(int32_t n, int32_t w, int32_t maxb, int32_t* offs, int32_t* cnts, int32_t cap) {

@@ -282,6 +282,11 @@ VP_API int vp_dbg_group_plan(int32_t n, int32_t w, int32_t maxb, int32_t* offs, 
  * 17 = 256 x 192, 18 = 192 x 256; wide != 0: 16-bit-output GEMMs (qkv, fc1), else the residual GEMMs; bm192_mask bits 1 / 2 as VP_G8_BM192, bit 4 = the
  * round-3 thresholds (as VP_G8_COST=0); *tiles (may be NULL) = its tile count */
 VP_API int vp_dbg_gemm8_pick(int32_t M, int32_t N, int32_t wide, int32_t bm192_mask, int32_t* tiles);
+/* HOST ONLY: which tile configuration of the 2-phase GEMM kernel (gemm.hip Cfg id: 8 / 11 = 192 x 128 with 4 / 8 waves, 1 = 128 x 128, 9 / 12 = 64 x 64 on a 2- / 4-stage
+ * ring, 15 = 128 x 64 3-stage, 30 / 31 = 64 x 64 / 32 x 64 with two k-blocks per barrier) the selection rule picks for one GEMM of the path: epi = 0 bias (qkv), 1 bias + GELU
+ * (fc1), 4 deconv, 5 final 1x1 conv, 6 residual + row statistics (attn.proj, mlp.fc2), 7 patch embed; [M, N] output, depth K; *group_m (may be NULL) = its tile-order group.
+ * (Large batches: the 8-phase kernel takes the encoder GEMMs over where vp_dbg_gemm8_pick says so.) */
+VP_API int vp_dbg_gemm2_pick(int32_t epi, int32_t M, int32_t N, int32_t K, int32_t* group_m);
 /* The two-phase schedule of a group call -- HOST ONLY, stub members: the order in which group_run would submit to (+ (member + 1)) and
  * wait for (- (member + 1)) its members for n crops on w devices of max_batch maxb.  Within every round all submissions precede the
  * first wait: no member's enqueue waits for another member's compute.  Returns the trace length (also beyond `cap`); < 0 on bad arguments. */
