@@ -138,6 +138,14 @@ struct vp_ctx {
                                       // 16-48 (every column tile merges its rows again): threshold 8.  VP_FOLD_STATS=n moves it (0 = always ln_finalize).
                                       // Round 2 merged per LANE in the epilogue (16 x redundant): slower than ln_finalize even at 8 crops (3.89 vs 2.97 ms).
     hipEvent_t ev_in = nullptr, ev_out = nullptr;   // vp_infer_device_stream: ordering against the caller's stream
+    // vp_infer_device_stream at small batches (round 5): the launches go onto the CALLER's stream (c->stream points at it for the duration of that call) instead of
+    // being fenced against it with two cross-stream events per call (~0.1 ms at 1-16 crops).  The handle's workspaces are then used from more than one stream over
+    // time: `adopt_stream` orders a call behind the previous one whenever the stream changes.
+    hipStream_t own_stream = nullptr;       // the handle's compute stream (== stream outside that call)
+    const void* last_stream_id = nullptr;   // identity of the caller's stream the workspaces were last used on (compared, never dereferenced: the caller may have destroyed it)
+    bool foreign_pending = false;           // the last user was a caller's stream: ev_sw, recorded behind its launches, is what work on any other stream waits for
+    hipEvent_t ev_sw = nullptr;
+    int caller_stream_max_n = 16;           // batches up to this many crops take that path (VP_CALLER_STREAM=0: off)
     uint8_t* frame_stage = nullptr;   // device copy of the current video frame (vp_infer_frame)
     size_t frame_cap = 0;
     int32_t* cparams = nullptr;       // per-crop geometry [max_batch, 8]
@@ -776,7 +784,7 @@ int run_chunk(vp_ctx* c, const void* d_src, int fmt, int nb, const int32_t* d_wh
         if ((rc = forward_chunk(c, d_src, fmt, nb, false))) return rc;
         return decode_chunk(c, d_wh, d_out, nb);
     };
-    if (nb > c->graph_max_n || c->prof != 0) return eager();
+    if (nb > c->graph_max_n || c->prof != 0 || c->stream == nullptr) return eager();   // (a caller's legacy default stream: plain launches; graph replay and eager launches run the same when calls are enqueued back to back)
     vp_ctx::GraphEntry* ge = nullptr;
     for (auto& g : c->graphs)
         if (g.n == nb && g.fmt == fmt && g.src == d_src && g.wh == d_wh && g.out == d_out) { ge = &g; break; }
@@ -798,11 +806,14 @@ int run_chunk(vp_ctx* c, const void* d_src, int fmt, int nb, const int32_t* d_wh
     // second sighting: capture.  Any failure of the capture machinery (not of the launches themselves) marks the key "do not
     // graph" and the chunk runs eagerly now and from now on -- a handle never gets stuck retrying a capture.
     hipGraph_t graph = nullptr;
+    hipStream_t target = c->stream;   // the capture itself always runs on the handle's own stream (nothing executes during a capture); the graph is launched on `target`
+    c->stream = c->own_stream;
     hipError_t e = hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal);
-    if (e != hipSuccess) { (void)hipGetLastError(); ge->no_graph = true; return eager(); }
+    if (e != hipSuccess) { c->stream = target; (void)hipGetLastError(); ge->no_graph = true; return eager(); }
     rc = forward_chunk(c, d_src, fmt, nb, false);
     if (!rc) rc = decode_chunk(c, d_wh, d_out, nb);
     e = hipStreamEndCapture(c->stream, &graph);
+    c->stream = target;
     if (rc) {   // a launch failed INSIDE the capture (e.g. a capture-illegal call): nothing has executed -- drop the graph, clear the sticky
                 // error and run the chunk eagerly, now and from now on; an error is reported only if the eager run fails too
         if (graph) hipGraphDestroy(graph);
@@ -830,14 +841,27 @@ int run_chunk(vp_ctx* c, const void* d_src, int fmt, int nb, const int32_t* d_wh
 
 size_t crop_bytes(int fmt) { return (size_t)3 * 256 * 192 * (fmt == VP_INPUT_F32_NCHW ? 4 : 1); }
 
-int check_ready(vp_ctx* c, int fmt, int n, const void* p0, const void* p1) {
+// Work on the handle's buffers is about to be enqueued on stream s: order it behind whatever the previous call left on ANOTHER stream.
+//   own -> own, caller A -> caller A: nothing (in-order streams);  own -> caller: record on own, caller waits;  caller -> own / another caller: wait for ev_sw,
+//   which vp_infer_device_stream recorded on the caller's stream behind its launches (that stream itself is never touched again: it may be gone).
+int adopt_stream(vp_ctx* c, hipStream_t s) {
+    if (!c->foreign_pending && s == c->own_stream) return VP_OK;
+    if (c->foreign_pending && (const void*)s == c->last_stream_id && s != c->own_stream) return VP_OK;
+    if (!c->ev_sw) HIPCHK(c, hipEventCreateWithFlags(&c->ev_sw, hipEventDisableTiming));
+    if (!c->foreign_pending) HIPCHK(c, hipEventRecord(c->ev_sw, c->own_stream));
+    HIPCHK(c, hipStreamWaitEvent(s, c->ev_sw, 0));
+    if (s == c->own_stream) c->foreign_pending = false;
+    return VP_OK;
+}
+
+int check_ready(vp_ctx* c, int fmt, int n, const void* p0, const void* p1, bool adopt_own = true) {
     if (!c) return VP_ERR_INVALID;
     if (!c->loaded) return fail(c, VP_ERR_STATE, "weights not loaded: call vp_load_weights first");
     if (fmt != VP_INPUT_F32_NCHW && fmt != VP_INPUT_U8_NHWC) return fail(c, VP_ERR_INVALID, "unknown input_format");
     if (n < 0 || (n > 0 && (!p0 || !p1))) return fail(c, VP_ERR_INVALID, "null buffer or negative batch");
     hipError_t e = hipSetDevice(c->cfg.device_id);
     if (e != hipSuccess) return fail(c, VP_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(e));
-    return VP_OK;
+    return adopt_own ? adopt_stream(c, c->own_stream) : VP_OK;   // every entry but the caller-stream path works on the handle's own stream
 }
 
 }  // namespace
@@ -878,6 +902,8 @@ int vp_create(vp_handle* out, const vp_config* cfg) {
     auto bail = [&](int rc) { g_create_error = c->err; vp_destroy(c); return rc; };
     if ((e = hipSetDevice(cfg->device_id)) != hipSuccess) { c->err = hipGetErrorString(e); return bail(VP_ERR_HIP); }
     if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) { c->err = hipGetErrorString(e); return bail(VP_ERR_HIP); }
+    c->own_stream = c->stream;
+    if (const char* f = getenv("VP_CALLER_STREAM")) c->caller_stream_max_n = atoi(f) == 1 ? 16 : atoi(f);   // 0 = always fence against the caller's stream with events
     const size_t B = (size_t)c->maxb;
     // fp8 mode: workspaces indexed by token row are sized for the padded row count the MXFP8 GEMM tiles need
     c->Mp = std::max<size_t>((B * 192 + 255) / 256 * 256, 512);
@@ -1031,9 +1057,26 @@ int vp_infer_device(vp_handle c, const void* d_crops, int32_t fmt, int32_t n, co
 }
 
 int vp_infer_device_stream(vp_handle c, const void* d_crops, int32_t fmt, int32_t n, const int32_t* d_org_wh, float* d_out, void* caller_stream) {
-    int rc = check_ready(c, fmt, n, d_crops, d_out);
+    int rc = check_ready(c, fmt, n, d_crops, d_out, false);
     if (rc) return rc;
     hipStream_t cs = (hipStream_t)caller_stream;
+    if (n > 0 && n <= c->caller_stream_max_n && n <= c->maxb && cs != c->own_stream) {
+        // Small batches: the chunk's launches (or its hipGraph) go onto the caller's stream itself -- in order with its producers and consumers by construction, no
+        // cross-stream dependency per call (two of them cost ~0.1 ms of a 0.6-2.4 ms step: profiles/small_batch_r5.txt).  ev_sw, recorded behind the launches, is
+        // what the next call on any other stream (and vp_synchronize / vp_destroy) waits for.
+        if ((rc = adopt_stream(c, cs))) return rc;
+        c->stream = cs;
+        rc = run_chunk(c, d_crops, fmt, n, d_org_wh, d_out);
+        c->stream = c->own_stream;
+        if (!c->ev_sw && hipEventCreateWithFlags(&c->ev_sw, hipEventDisableTiming) != hipSuccess) return fail(c, VP_ERR_HIP, "hipEventCreateWithFlags(ev_sw)");
+        const hipError_t er = hipEventRecord(c->ev_sw, cs);   // also when rc != 0: part of the chunk may be enqueued
+        c->foreign_pending = true;
+        c->last_stream_id = (const void*)cs;
+        if (rc) return rc;
+        if (er != hipSuccess) return fail(c, VP_ERR_HIP, std::string("hipEventRecord(ev_sw): ") + hipGetErrorString(er));
+        return VP_OK;
+    }
+    if ((rc = adopt_stream(c, c->own_stream))) return rc;
     if (!c->ev_in) HIPCHK(c, hipEventCreateWithFlags(&c->ev_in, hipEventDisableTiming));
     if (!c->ev_out) HIPCHK(c, hipEventCreateWithFlags(&c->ev_out, hipEventDisableTiming));
     // everything the caller enqueued on its stream so far (the producers of d_crops / d_org_wh) happens before the library's kernels ...
@@ -1527,6 +1570,7 @@ void* vp_stream(vp_handle c) { return c ? (void*)c->stream : nullptr; }
 int vp_synchronize(vp_handle c) {
     if (!c) return VP_ERR_INVALID;
     HIPCHK(c, hipSetDevice(c->cfg.device_id));
+    if (c->foreign_pending && c->ev_sw) HIPCHK(c, hipEventSynchronize(c->ev_sw));   // the last call ran on a caller's stream
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return VP_OK;
 }
@@ -1562,12 +1606,14 @@ int vp_profile_kernel(vp_handle c, int32_t family, char* buf, int32_t cap) {
 int vp_destroy(vp_handle c) {
     if (!c) return VP_OK;
     hipSetDevice(c->cfg.device_id);
+    if (c->foreign_pending && c->ev_sw) hipEventSynchronize(c->ev_sw);
     if (c->stream) hipStreamSynchronize(c->stream);
     for (auto& e : c->evs) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
     for (auto& p : c->ev_pool) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
     for (auto& sl : c->slots) { if (sl.h2d) hipEventDestroy(sl.h2d); if (sl.done) hipEventDestroy(sl.done); if (sl.out) hipEventDestroy(sl.out); if (sl.host_kp) hipHostFree(sl.host_kp); if (sl.host_in) hipHostFree(sl.host_in); }
     if (c->ev_in) hipEventDestroy(c->ev_in);
     if (c->ev_out) hipEventDestroy(c->ev_out);
+    if (c->ev_sw) hipEventDestroy(c->ev_sw);
     for (auto& ge : c->graphs) if (ge.exec) hipGraphExecDestroy(ge.exec);
     for (void* p : c->allocs) hipFree(p);
     if (c->copy_stream) { hipStreamSynchronize(c->copy_stream); hipStreamDestroy(c->copy_stream); }

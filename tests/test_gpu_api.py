@@ -39,6 +39,50 @@ def test_infer_device_is_ordered_after_torch_producers():
     eng.close()
 
 
+def test_small_batch_ordered_entry_runs_on_the_callers_stream(monkeypatch):
+    """Round 5: at <= 16 crops vp_infer_device_stream enqueues the chunk (eager launches on torch's legacy default stream, the hipGraph on any other stream) on the
+    CALLER's stream instead of fencing its own stream against it with two events per call.  The handle's workspaces are then shared between streams over time: calls
+    alternate between torch's default stream, a side stream, the handle's own stream (un-ordered device entry) and the host entry with nothing but the library's own
+    ordering between them -- every result must be the host-path result, consumers enqueued right behind a call must see finished keypoints, and VP_CALLER_STREAM=0
+    (the event-fenced path of rounds 2-4) must give the same bits."""
+    import torch
+    shp, sd, _ = weights('s', 'coco')
+    crops = synthetic_crops(4, 5, 'blobs')
+    dev = torch.device('cuda', 0)
+    for mode in ('1', '0'):
+        monkeypatch.setenv('VP_CALLER_STREAM', mode)
+        eng = VitPoseHip(shp, sd, dtype='fp16', max_batch=8)
+        ref = eng.infer(crops)
+        side = torch.cuda.Stream(device=dev)
+        d = torch.from_numpy(crops).to(dev)
+        torch.cuda.synchronize()
+        for it in range(4):
+            o0 = torch.full((4, 17, 3), float('nan'), device=dev)
+            eng.infer_device(d, o0, sync=False)                          # torch's default stream
+            s0 = o0.sum()
+            with torch.cuda.stream(side):
+                side.wait_stream(torch.cuda.current_stream(dev))
+                o1 = torch.full((4, 17, 3), float('nan'), device=dev)
+                eng.infer_device(d, o1, sync=False)                      # a side stream: ordered behind the default-stream call by the library alone
+                s1 = o1.sum()
+            o2 = torch.full((4, 17, 3), float('nan'), device=dev)
+            torch.cuda.current_stream(dev).synchronize()                 # o2's fill is done (the un-ordered entry's contract); the side stream's call may still be running
+            eng.infer_device(d, o2, sync=True, ordered=False)            # the handle's own stream, right behind the side-stream call on the same workspaces
+            host = eng.infer(crops)                                      # host entry
+            side.synchronize()
+            torch.cuda.synchronize()
+            assert torch.isfinite(s0).item() and torch.isfinite(s1).item(), (mode, it)
+            for name, o in (('default stream', o0), ('side stream', o1), ('own stream', o2)):
+                assert np.array_equal(o.cpu().numpy(), ref), (mode, it, name)
+            assert np.array_equal(host, ref), (mode, it)
+        o3 = torch.full((4, 17, 3), float('nan'), device=dev)
+        with torch.cuda.stream(side):
+            eng.infer_device(d, o3, sync=False)
+        eng.synchronize()                                                # vp_synchronize covers work left on a caller's stream
+        assert np.array_equal(o3.cpu().numpy(), ref), mode
+        eng.close()
+
+
 def test_async_host_path_matches_sync_path():
     shp, sd, _ = weights('s', 'coco')
     eng = VitPoseHip(shp, sd, dtype='fp16', max_batch=16)
