@@ -40,13 +40,39 @@ PEAK_HBM = 8.0e12
 PEAK_MFMA_FP8 = 5.0e15    # dense fp8 (MX-scaled K = 128) MFMA peak, MI355X_MICROARCH.md
 
 
-def cpu_baseline(variant, dataset, budget_s=15.0):
+def physical_cores():
+    """Distinct (package, core) pairs of /proc/cpuinfo among the CPUs this process may run on; None when the file has no topology."""
+    try:
+        allowed = os.sched_getaffinity(0)
+    except AttributeError:
+        allowed = None
+    cores, cpu, pkg = set(), None, 0
+    try:
+        for line in open('/proc/cpuinfo'):
+            k, _, v = line.partition(':')
+            k, v = k.strip(), v.strip()
+            if k == 'processor':
+                cpu, pkg = int(v), 0
+            elif k == 'physical id':
+                pkg = int(v)
+            elif k == 'core id' and (allowed is None or cpu in allowed):
+                cores.add((pkg, int(v)))
+    except (OSError, ValueError):
+        return None
+    return len(cores) or None
+
+
+def cpu_baseline(variant, dataset, budget_s=15.0, probe_crops=8):
     """Reference-equivalent CPU path (oracle/ restatement of _inference_torch, per crop,
     batch 1 exactly like VitInference) on a bounded sample of the same synthetic crops.
 
     torch's default of one thread per hardware thread is pathological for batch-1 ViT
     GEMMs on a many-core host (measured 0.03 persons/s with 256 threads), so a few
-    thread counts are probed on 2 crops each and the best one is used and reported."""
+    thread counts -- never more than the physical cores -- are probed and the best one
+    is used.  The probe is `probe_crops` crops per candidate after two warm-up crops and
+    ranks candidates by their MEDIAN crop time (round 5 probed two crops each and moved
+    37 % between rounds on an unchanged oracle: VERDICT r5 "What's weak" 11); every
+    probed rate is printed in `sample`."""
     import torch
     from easy_vitpose_amd.configs import model_shape
     from easy_vitpose_amd.synth import synthetic_crops, synthetic_state_dict
@@ -55,28 +81,37 @@ def cpu_baseline(variant, dataset, budget_s=15.0):
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
         avail = os.cpu_count() or 1
+    phys = physical_cores() or avail
     shp = model_shape(variant, dataset)
     sd = O.to_torch_state_dict(synthetic_state_dict(shp, 0))
     crops = synthetic_crops(256, 0, 'noise')
     run = lambda i: O.inference_torch(sd, shp.depth, shp.num_heads, crops[i])
-    best_t, best_dt = None, None
-    for t in sorted({min(avail, c) for c in (8, 16, 32, 64)}):
+    cap = max(1, min(avail, phys))
+    probed = {}
+    for t in sorted({min(cap, c) for c in (8, 16, 32, 64)}):
         torch.set_num_threads(t)
-        run(0)
-        t0 = time.perf_counter(); run(1); run(2); dt = (time.perf_counter() - t0) / 2
-        if best_dt is None or dt < best_dt:
-            best_t, best_dt = t, dt
-        if dt > 3.0:
+        run(0); run(1)
+        ts = []
+        for i in range(probe_crops):
+            t0 = time.perf_counter(); run(2 + i); ts.append(time.perf_counter() - t0)
+            if sum(ts) > 12.0:
+                break
+        probed[t] = float(np.median(ts))
+        if probed[t] > 3.0:
             break
+    best_t = min(probed, key=probed.get)
     torch.set_num_threads(best_t)
     n, t0 = 0, time.perf_counter()
     while n < len(crops) and (time.perf_counter() - t0 < budget_s or n < 3):
         run(n)
         n += 1
     dt = time.perf_counter() - t0
+    rates = ', '.join(f'{t} threads {1.0 / v:.1f}/s' for t, v in sorted(probed.items()))
     return {'value': round(n / dt, 3), 'unit': 'persons/s', 'cores': best_t, 'kind': 'port',
             'sample': f'{n} crops of the same workload, one at a time (pre_img -> torch fp32 model -> decode), '
-                      f'{dt:.1f} s, torch {torch.__version__} with {best_t} threads (best of 8/16/32/64; host has {avail} hw threads)'}
+                      f'{dt:.1f} s, torch {torch.__version__} with {best_t} threads; probe (median of {probe_crops} crops each): {rates}; '
+                      f'host has {avail} hw threads on {phys} physical cores',
+            'probe_persons_per_sec': {str(t): round(1.0 / v, 2) for t, v in sorted(probed.items())}}
 
 
 def cpu_baseline_batched(variant, dataset, threads, batch=16, budget_s=12.0):
@@ -129,7 +164,10 @@ class Harness:
         self.rank = dist.get_rank() if self.use_dist else 0
 
     def step(self):
-        self.eng.infer_device(self.d_crops, self.d_out, sync=self.use_dist)      # library stream; sync hands over to torch's stream
+        # stream-ordered entry (vp_infer_device_stream): the library's kernels are ordered behind torch's current stream and torch work enqueued
+        # afterwards waits for them ON THE DEVICE -- the all-gather queues behind the keypoints with no host synchronisation (SURVEY.md 8e:
+        # "enqueue on each device's compute stream ... no host sync"); the host blocks only in fence()
+        self.eng.infer_device(self.d_crops, self.d_out, sync=False)
         if self.use_dist:
             self.dist.all_gather_into_tensor(self.d_all, self.d_out)             # RCCL over xGMI, [world*B, K, 3]
 
@@ -202,7 +240,8 @@ def strong_scaling_config4(world, rank, dev, dtype, steps=100, warmup=10, n_tota
         eng, crops, K = engine_factory(per, lo, hi)
         device_sync = device_sync or (lambda: None)
     local = torch.zeros((per, K, 3), dtype=torch.float32, device=dev)
-    sp = ShardedPose(lambda shard, wh: eng.infer_device(shard, local[:len(shard)], sync=True), K, device=dev, reuse_buffers=True)
+    # sync=False: the stream-ordered entry orders the all-gather behind the keypoints on the device; the host never blocks inside a frame
+    sp = ShardedPose(lambda shard, wh: eng.infer_device(shard, local[:len(shard)], sync=False), K, device=dev, reuse_buffers=True)
     out = {}
 
     def frame():

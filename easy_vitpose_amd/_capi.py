@@ -26,7 +26,7 @@ SYMBOLS = ['vp_abi_version', 'vp_create', 'vp_load_weights', 'vp_infer', 'vp_inf
            'vp_group_infer_allgather', 'vp_group_destroy', 'vp_group_last_error', 'vp_infer_frame', 'vp_infer_flip', 'vp_infer_heatmaps',
            'vp_infer_tokens', 'vp_decode_only', 'vp_stream', 'vp_synchronize', 'vp_set_profiling',
            'vp_reset_profile', 'vp_get_profile', 'vp_profile_kernel', 'vp_group_peer_access_missing', 'vp_destroy', 'vp_last_error',
-           'vp_dbg_gemm', 'vp_dbg_attention', 'vp_dbg_layernorm', 'vp_dbg_deconv', 'vp_dbg_gemm_bench', 'vp_dbg_gemm_case', 'vp_dbg_gemm_bench2', 'vp_dbg_gemm_compare', 'vp_dbg_peak', 'vp_dbg_crop_prep',
+           'vp_dbg_gemm', 'vp_dbg_attention', 'vp_dbg_layernorm', 'vp_dbg_deconv', 'vp_dbg_gemm_case', 'vp_dbg_crop_prep',
            'vp_dbg_group_plan', 'vp_dbg_group_trace', 'vp_dbg_gemm8_pick', 'vp_dbg_gemm2_pick', 'vp_dbg_fp8_gemm', 'vp_dbg_mx_gemm', 'vp_dbg_host_e4m3', 'vp_dbg_gemm_fp8_case', 'vp_dbg_qkvattn']
 
 
@@ -116,15 +116,17 @@ def load_library():
     lib.vp_dbg_deconv.argtypes = [C.c_int32] * 6 + [C.c_void_p, C.POINTER(vp_tensor_desc), C.c_int32, C.c_void_p]
     lib.vp_infer_flip.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
                                   C.c_void_p, C.c_void_p]
-    lib.vp_dbg_gemm_bench.argtypes = [C.c_int32] * 9 + [C.POINTER(C.c_float)]
     lib.vp_dbg_gemm_case.argtypes = [C.c_int32] * 9 + [C.c_void_p] * 8
-    lib.vp_dbg_gemm_bench2.argtypes = [C.c_int32] * 10 + [C.POINTER(C.c_float)]
-    lib.vp_dbg_gemm_compare.argtypes = [C.c_int32] * 13 + [C.POINTER(C.c_uint64), C.POINTER(C.c_double)]
     if hasattr(lib, 'vp_dbg_gemm8_timeline'):   # the measurement build (include/vitpose_hip_tools.h; tools/ point VP_HIP_LIB at it)
         lib.vp_dbg_gemm8_timeline.argtypes = [C.c_int32] * 9 + [C.POINTER(C.c_uint64), C.c_int32]
         lib.vp_dbg_gemm_timeline.argtypes = [C.c_int32] * 6 + [C.POINTER(C.c_uint64), C.c_int32]
         lib.vp_dbg_gemm8_timeline.restype = lib.vp_dbg_gemm_timeline.restype = C.c_int
-    lib.vp_dbg_peak.argtypes = [C.c_int32, C.c_int32, C.POINTER(C.c_double)]
+        lib.vp_dbg_gemm_bench.argtypes = [C.c_int32] * 9 + [C.POINTER(C.c_float)]
+        lib.vp_dbg_gemm_bench2.argtypes = [C.c_int32] * 10 + [C.POINTER(C.c_float)]
+        lib.vp_dbg_gemm_compare.argtypes = [C.c_int32] * 13 + [C.POINTER(C.c_uint64), C.POINTER(C.c_double)]
+        lib.vp_dbg_peak.argtypes = [C.c_int32, C.c_int32, C.POINTER(C.c_double)]
+        for n_ in ('vp_dbg_gemm_bench', 'vp_dbg_gemm_bench2', 'vp_dbg_gemm_compare', 'vp_dbg_peak'):
+            getattr(lib, n_).restype = C.c_int
     lib.vp_profile_kernel.argtypes = [H, C.c_int32, C.c_char_p, C.c_int32]
     lib.vp_group_peer_access_missing.argtypes = [H]
     lib.vp_dbg_group_plan.argtypes = [C.c_int32] * 3 + [C.c_void_p, C.c_void_p, C.c_int32]

@@ -26,9 +26,10 @@ CSRC = os.path.join(HERE, 'csrc')
 LIBDIR = os.path.join(HERE, '_lib')
 LIB = os.path.join(LIBDIR, 'libvitpose_hip.so')
 TOOLS_LIB = os.path.join(LIBDIR, 'libvitpose_hip_tools.so')
-SOURCES = ['gemm.hip', 'gemm8.hip', 'gemm8f.hip', 'qkvattn.hip', 'quant8.hip', 'attention.hip', 'elementwise.hip', 'decode.hip', 'fp8_probe.hip', 'vitpose_api.hip']
+SOURCES = ['gemm.hip', 'gemm8.hip', 'gemm8f.hip', 'qkvattn.hip', 'quant8.hip', 'attention.hip', 'elementwise.hip', 'decode.hip', 'fp8_probe.hip',
+           'vitpose_api.hip', 'weights.hip', 'tile_rules.hip', 'debug_taps.hip']
 TOOLS_SOURCES = SOURCES
-HEADERS = ['common.h', 'kernels.h', 'gemm8_common.h', 'mx8.h', os.path.join('..', '..', 'include', 'vitpose_hip.h'),
+HEADERS = ['common.h', 'kernels.h', 'gemm8_common.h', 'mx8.h', 'api_internal.h', os.path.join('..', '..', 'include', 'vitpose_hip.h'),
            os.path.join('..', '..', 'include', 'vitpose_hip_tools.h')]
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-fvisibility=hidden',
          '-ffp-contract=fast', '-Wno-unused-result']

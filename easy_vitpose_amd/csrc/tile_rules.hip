@@ -1,0 +1,114 @@
+// Tile rules: which kernel configuration runs one GEMM of the path -- pure host functions of the shape (no device, no handle), walked over
+// every batch size of every model by tests/test_host_logic.py through the host-only taps at the end of this file.
+#include "api_internal.h"
+
+using namespace vpi;
+
+namespace vpi {
+
+// Tile of the 8-phase kernel for an [M, N] output (wide = 16-bit output, else residual epilogue); variant 0 = the 2-phase kernels run it.
+// A pure function of the shape: tests/test_host_logic.py walks it over every batch size through the host-only tap vp_dbg_gemm8_pick.
+//
+// A candidate QUALIFIES (round 3, measured in situ at batch 32 - 256: ViTPose-B qkv at 216 / 432 tiles -15 % / -5 %, fc2 at 216 tiles -23 %, but
+// fc1 / fc2 at 288 tiles = 56 % full +20 %; ViTPose-H fc2 at batch 128, 480 tiles: 329 -> 279 us) from 1.75 tiles per CU (448), or from 192 tiles
+// when its last round is >= 80 % full.  Round 4 (`extended`; profiles/tile_sweep_r4.txt: isolated sweep + in-situ A/B at 40 - 256 crops) adds, from
+// 7 680 rows on: a launch of ONE round from 192 tiles (fc2 at 88 crops: 198 tiles of 256 x 256, 110 -> 87 us), and a candidate whose
+// rounds x tile area is below the 2-phase kernel's rounds x work of a CU per round (two 192 x 128 workgroups per CU; one when <= 256 tiles) --
+// fc2 at 172 crops: 387 tiles of 256 x 256 = 2 rounds against 3 rounds of everything else, 200 -> 173 us.  Among the qualifying candidates the
+// cheapest rounds x area wins (192 x 256 priced x 1.08: measured 1 - 8 % behind 256 x 192 at equal rounds; ties: the larger tile); without
+// `extended` the 192 x 256 tile is only the fallback when no 256-row tile qualifies.  Where isolated and in-situ timings disagreed (fc2 at 52 / 128
+// crops, ViTPose-L at 40, -S at 256: the 2-phase kernel finds `hid` in the caches and wins by 2 - 7 % in situ) the rule follows the in-situ result.
+G8Pick pick_gemm8_tile(int M, int N, bool wide, int bm192_mask, long min_tiles, bool extended) {
+    struct Cand { int bm, bn, variant; };
+    static const Cand cands[3] = {{256, 256, 16}, {256, 192, 17}, {192, 256, 18}};
+    const bool ext = extended && M >= 7680;
+    const long t2 = (long)((M + 191) / 192) * ((N + 127) / 128);
+    const double cost2 = t2 <= 256 ? 24576.0 : (double)((t2 + 511) / 512) * 49152.0;
+    G8Pick pk{0, 0, 0, 0};
+    double best = 0.0;
+    bool have256 = false;
+    for (int i = 0; i < 3; ++i) {
+        const Cand& cd = cands[i];
+        if (M % cd.bm || N % cd.bn || (wide && cd.variant == 17)) continue;
+        if (cd.variant == 18 && (!(bm192_mask & (wide ? 2 : 1)) || (!ext && have256))) continue;   // round-3 behaviour: only when no 256-row tile qualifies
+        const long t = (long)(M / cd.bm) * (N / cd.bn);
+        if (t < 8) continue;
+        const long rounds = (t + 255) / 256;
+        const double f = (double)t / (double)(rounds * 256);   // share of 256 CUs x rounds that computes a tile (below 256 tiles: one workgroup per tile)
+        const double cost = (double)rounds * cd.bm * cd.bn * (cd.variant == 18 ? 1.08 : 1.0);
+        bool q = t >= min_tiles || (f >= 0.8 && t >= 192);
+        if (ext) q = q || (rounds == 1 && t >= 192) || cost < 0.95 * cost2;
+        if (!q) continue;
+        if (cd.bm == 256) have256 = true;
+        if (!pk.variant || (ext ? cost < 0.98 * best : f > (double)pk.tiles / (double)((pk.tiles + 255) / 256 * 256) + 1e-9)) {
+            pk = {cd.variant, cd.bm, cd.bn, t};
+            best = cost;
+        }
+    }
+    return pk;
+}
+
+// Tile configuration of the 2-phase kernel (gemm.hip Cfg id) for one GEMM of the path -- a pure function of the epilogue and the shape: tests/test_host_logic.py
+// walks it over every batch size of every model through the host-only tap vp_dbg_gemm2_pick (slots, rounds, the PIPE-6 precondition, the measured choices).
+//
+// Default: the 192(m) x 128(n) tile -- M is always a multiple of 192 tokens (one crop per m-tile), so the tile count divides evenly over 256 CUs x 2 workgroups at
+// the BASELINE batch; best or tied for every encoder GEMM in the MI355X sweep (profiles/gemm_tune_r1.txt); residual GEMMs: the same tile as 8 waves; wide GEMMs use
+// the grouped order.  Small batches (fewer than 384 such tiles, e.g. 8 crops per GPU of a sharded frame): tiles that still give the 256 CUs a workgroup each --
+// 128 x 128 from 256 tiles on, else 64 x 64, and inside the 64 x 64 regime (round 5, measured IN SITU: tools/small_sweep.py, profiles/small_batch_r5.txt):
+//   64 x 64 tiles are bound by the latency of every k-block (a workgroup retires STAGES - 1 k-blocks per round trip) and, with one workgroup per SIMD set, by the
+//   ~500 cycles of wait + barrier + LDS round trip in front of the 8 MFMAs of a k-step.  Inside the step every layer's weights are first touched from HBM, so the round
+//   trip is ~2 x what the isolated sweeps of rounds 2-3 (weights L2-resident) saw.  Every choice keeps the k order: bit-identical.
+//   * <= 256 tiles of 32 x 64: Cfg31 = 32(m) x 64(n) tiles, 6-stage ring, TWO k-blocks per barrier (gemm.hip PIPE 6) -- twice the workgroups, half the MFMAs per wave
+//     and k-block;  <= 256 tiles of 64 x 64: Cfg30 = that schedule on 64 x 64 tiles, one workgroup per CU;
+//   * <= 512 tiles (all resident at the 2 workgroups per CU of the 4-stage ring): Cfg12; more tiles would run the deep rings in two rounds and lose against the 5
+//     workgroups per CU of the 2-stage ring (Cfg9) -- except for long K (round 2: Cfg12 from K = 2048 on);
+//   * residual GEMMs (attn.proj, mlp.fc2) with more than 512 tiles of 64 x 64 but <= 512 of 128(m) x 64(n) (12-28 crops): Cfg15 = that tile on a 3-stage ring, all
+//     resident at 2 workgroups per CU: fc2 of 16 crops 42 -> 34 us (-B), 56.5 -> 44 (-L), of 12 crops 72 -> 54 (-H).  For the wide GEMMs the same tile is neutral.
+//   attn.proj of 1-8 crops 17-20 -> 10-13 us, mlp.fc2 of one crop 24.5 -> 17-21.5 us, qkv / fc1 of one crop 18 -> 12 us; ViTPose-L 1 crop 1.90 -> 1.36 ms, 8 crops
+//   2.50 -> 2.40 ms, 16 crops 3.62 -> 3.23 ms; -B 1 crop 0.73 -> 0.56 ms, 16 crops 1.48 -> 1.33 ms; -H 1 crop 3.00 -> 2.17 ms, 12 crops 5.49 -> 4.81 ms.
+Tile2Pick pick_gemm2_tile(int epi, int M, int N, int K) {
+    Tile2Pick tp;
+    tp.variant = (epi == vp::EPI_BIAS_RESID || epi == vp::EPI_BIAS_RESID_LN) ? 11 : 8;
+    tp.group_m = (epi == vp::EPI_BIAS || epi == vp::EPI_BIAS_GELU) ? 8 : 0;
+    const long par_ = (epi == vp::EPI_DECONV) ? 4 : 1;   // the four output parities of a deconv are four GEMMs of one launch
+    const long t192 = (long)((M + 191) / 192) * ((N + 127) / 128) * par_;
+    const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128) * par_;
+    if (t192 >= 384) return tp;
+    tp.variant = (t128 >= 256) ? 1 : 9;
+    tp.group_m = 0;
+    if (tp.variant == 9) {
+        const long t64 = (long)((M + 63) / 64) * ((N + 63) / 64) * par_;
+        const long t32 = (long)((M + 31) / 32) * ((N + 63) / 64) * par_;
+        const long t128x64 = (long)((M + 127) / 128) * ((N + 63) / 64) * par_;
+        if (K % 128 == 0 && t32 <= 256) tp.variant = 31;
+        else if (K % 128 == 0 && t64 <= 256) tp.variant = 30;
+        else if (t64 <= 512) tp.variant = 12;
+        else if (epi == vp::EPI_BIAS_RESID_LN && t128x64 <= 512) tp.variant = 15;
+        else if (K >= 2048) tp.variant = 12;
+    }
+    return tp;
+}
+
+}  // namespace vpi
+
+extern "C" {
+
+// HOST ONLY: the 8-phase tile the selection rule of gemm() picks for an [M, N] output (wide: qkv / fc1; else the residual GEMMs); returns the
+// variant (0 = none: 2-phase kernels, 16 = 256 x 256, 17 = 256 x 192, 18 = 192 x 256) and its tile count
+VP_API int vp_dbg_gemm8_pick(int32_t M, int32_t N, int32_t wide, int32_t bm192_mask, int32_t* tiles) {
+    if (M <= 0 || N <= 0) return VP_ERR_INVALID;
+    const G8Pick pk = pick_gemm8_tile(M, N, wide != 0, bm192_mask & 3, 448, !(bm192_mask & 4));
+    if (tiles) *tiles = (int32_t)pk.tiles;
+    return pk.variant;
+}
+
+// HOST ONLY: the tile configuration (gemm.hip Cfg id) the 2-phase selection rule picks for one GEMM: epi = kernels.h GemmEpi (0 bias, 1 bias + GELU, 4 deconv, 5 heatmap,
+// 6 residual + statistics, 7 pos + statistics), shape [M, N] x K; *group_m = its tile-order group
+VP_API int vp_dbg_gemm2_pick(int32_t epi, int32_t M, int32_t N, int32_t K, int32_t* group_m) {
+    if (M <= 0 || N <= 0 || K <= 0) return VP_ERR_INVALID;
+    const Tile2Pick tp = pick_gemm2_tile(epi, M, N, K);
+    if (group_m) *group_m = tp.group_m;
+    return tp.variant;
+}
+
+}  // extern "C"

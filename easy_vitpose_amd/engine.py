@@ -113,10 +113,15 @@ class VitPoseHip:
         return out
 
     def infer_device(self, d_crops, d_out, org_wh=None, sync: bool = True, ordered: bool = True):
-        """Device-resident torch tensors in/out (no copies).  The kernels run on the library's own stream; with `ordered`
-        (default) they are ordered after everything already enqueued on torch's CURRENT stream (the producers of `d_crops`)
-        and torch work enqueued afterwards waits for them (vp_infer_device_stream) -- `d_out` can be consumed by the next
-        torch op without a host synchronisation.  `sync` additionally blocks the host until the result is complete."""
+        """Device-resident torch tensors in/out (no copies).  With `ordered` (default) the call goes through the stream-ordered entry
+        (vp_infer_device_stream, contract in include/vitpose_hip.h): the library's kernels are ordered after everything already
+        enqueued on torch's CURRENT stream (the producers of `d_crops`) and torch work enqueued afterwards waits for them -- `d_out`
+        can be consumed by the next torch op without a host synchronisation.  WHERE the kernels run depends on the batch: up to 16
+        crops (`VP_CALLER_STREAM`) they are launched on torch's current stream itself -- work the caller enqueues on that stream
+        afterwards runs BEHIND them, not beside them, and the handle stays busy on that stream until the next call, `synchronize()` or
+        `close()`; larger batches run on the library's own stream, fenced against the caller's with two events (work enqueued on the
+        caller's stream afterwards waits for them too, other streams overlap freely).  `sync` additionally blocks the host until the
+        result is complete.  `ordered=False`: the library's own stream with no ordering against torch's streams (vp_infer_device)."""
         import torch
         assert d_crops.is_cuda and d_out.is_cuda and d_crops.is_contiguous() and d_out.is_contiguous()
         fmt = capi.VP_INPUT_U8_NHWC if d_crops.dtype == torch.uint8 else capi.VP_INPUT_F32_NCHW

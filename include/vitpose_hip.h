@@ -257,25 +257,13 @@ VP_API int vp_dbg_deconv(int32_t device_id, int32_t dtype, int32_t B, int32_t Hi
 /* the device crop / zero-pad / resize kernel alone: uint8 crops [n, 256, 192, 3] */
 VP_API int vp_dbg_crop_prep(int32_t device_id, const uint8_t* frame, int32_t fh, int32_t fw, const int32_t* crop_params,
                             int32_t n, uint8_t* out);
-/* average milliseconds of `iters` launches of one GEMM tile configuration on random device operands */
-VP_API int vp_dbg_gemm_bench(int32_t device_id, int32_t dtype, int32_t epi, int32_t variant, int32_t group_m,
-                             int32_t M, int32_t N, int32_t K, int32_t iters, float* ms_out);
-/* production GEMM configurations on RANDOM device operands (tools/gemm8_check.py, tests/test_gpu_gemm_cfgs.py):
- * epi = 0 bias, 1 bias+gelu, 2 bias+residual (fp32), 3 pos (fp32), 6 bias + two-plane residual + LayerNorm row statistics;
- * variant = tile configuration (gemm.hip Cfg0-11; 16 / 17 = the 8-phase kernel of gemm8.hip with 256x256 / 256x192 tiles);
- * flags: 1 persistent workgroups, 2 64x64-blocked output, 4 64x64-blocked A operand, 8 reversed tile walk, 16 LayerNorm-consumer fold.
- * bench2: average milliseconds per launch.  compare: both configurations on the same operands, `reps` times; counts every
- * differing output element / statistic (two kernels with the same accumulation order must agree bit for bit). */
-/* one launch of a production configuration on HOST data (layouts built / undone inside): epi 0-3, 5 (final 1x1 conv with hi+lo
+/* one launch of a production GEMM configuration on HOST data (layouts built / undone inside): variant = tile configuration (gemm.hip Cfg id;
+ * 16 / 17 / 18 = the 8-phase kernel of gemm8.hip with 256x256 / 256x192 / 192x256 tiles); flags: 1 persistent workgroups, 2 64x64-blocked output,
+ * 4 64x64-blocked A operand, 8 reversed tile walk, 16 LayerNorm-consumer fold; epi 0-3, 5 (final 1x1 conv with hi+lo
  * weights -> heatmaps [M/3072, N, 3072]), 6, 7; rowstat [M,2] + ln_s [N] = LayerNorm-consumer fold; stats [M, N/64, 2] (epi 6 / 7) */
 VP_API int vp_dbg_gemm_case(int32_t device_id, int32_t dtype, int32_t epi, int32_t variant, int32_t group_m, int32_t flags,
                             int32_t M, int32_t N, int32_t K, const float* A, const float* W, const float* bias, const float* aux,
                             const float* rowstat, const float* ln_s, float* out, float* stats);
-VP_API int vp_dbg_gemm_bench2(int32_t device_id, int32_t dtype, int32_t epi, int32_t variant, int32_t group_m, int32_t flags,
-                              int32_t M, int32_t N, int32_t K, int32_t iters, float* ms_out);
-VP_API int vp_dbg_gemm_compare(int32_t device_id, int32_t dtype, int32_t epi, int32_t variant_a, int32_t group_a, int32_t flags_a,
-                               int32_t variant_b, int32_t group_b, int32_t flags_b, int32_t M, int32_t N, int32_t K, int32_t reps,
-                               uint64_t* n_mismatch, double* max_abs_diff);
 /* The sharding plan of vp_group_infer for n crops on w devices of max_batch maxb -- HOST ONLY, no device needed: the exact
  * function group_run executes.  Rounds of w * maxb crops; inside a round device i takes [off, off + cnt) with ceil(nr / w) crops
  * per device (trailing devices short or empty).  Entry e = round * w + device: offs[e], cnts[e].  Returns the number of
@@ -316,8 +304,6 @@ VP_API int vp_dbg_gemm_fp8_case(int32_t device_id, int32_t epi, int32_t M, int32
                                 const float* aux, float* out, float* stats, float* a_deq, float* w_deq);
 /* HOST ONLY: fp32 -> OCP e4m3 codes with the converter the fp8 weight packer uses (round to nearest even, saturating at 448) */
 VP_API int vp_dbg_host_e4m3(const float* in, uint8_t* out, int64_t n);
-/* calibration of the box: kind 0/1 = MFMA-only loop 16x16x32 / 32x32x16 f16 (TFLOP/s), 2 = float4 copy (TB/s) */
-VP_API int vp_dbg_peak(int32_t device_id, int32_t kind, double* result);
 
 #ifdef __cplusplus
 }

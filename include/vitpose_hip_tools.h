@@ -31,6 +31,25 @@ VP_API int vp_dbg_qkvattn_bench(int32_t device_id, int32_t npairs, int32_t D, in
  * workgroup of a `blocks` x `threads` launch with `lds_bytes` of dynamic LDS whose workgroups stay resident for ~spin x 4096 cycles. */
 VP_API int vp_dbg_hwid_probe(int32_t device_id, int32_t blocks, int32_t threads, int32_t lds_bytes, int32_t spin, uint32_t* out);
 
+/* ---- timing taps (moved out of the product library in round 6: the product .so exports parity taps only) ---- */
+/* average milliseconds of `iters` launches of one GEMM tile configuration on random device operands */
+VP_API int vp_dbg_gemm_bench(int32_t device_id, int32_t dtype, int32_t epi, int32_t variant, int32_t group_m,
+                             int32_t M, int32_t N, int32_t K, int32_t iters, float* ms_out);
+/* production GEMM configurations on RANDOM device operands (tools/gemm8_check.py, tests/test_gpu_gemm_cfgs.py):
+ * epi = 0 bias, 1 bias+gelu, 2 bias+residual (fp32), 3 pos (fp32), 6 bias + two-plane residual + LayerNorm row statistics;
+ * variant = tile configuration (gemm.hip Cfg0-11; 16 / 17 = the 8-phase kernel of gemm8.hip with 256x256 / 256x192 tiles);
+ * flags: 1 persistent workgroups, 2 64x64-blocked output, 4 64x64-blocked A operand, 8 reversed tile walk, 16 LayerNorm-consumer fold.
+ * bench2: average milliseconds per launch.  compare: both configurations on the same operands, `reps` times; counts every
+ * differing output element / statistic (two kernels with the same accumulation order must agree bit for bit). */
+VP_API int vp_dbg_gemm_bench2(int32_t device_id, int32_t dtype, int32_t epi, int32_t variant, int32_t group_m, int32_t flags,
+                              int32_t M, int32_t N, int32_t K, int32_t iters, float* ms_out);
+VP_API int vp_dbg_gemm_compare(int32_t device_id, int32_t dtype, int32_t epi, int32_t variant_a, int32_t group_a, int32_t flags_a,
+                               int32_t variant_b, int32_t group_b, int32_t flags_b, int32_t M, int32_t N, int32_t K, int32_t reps,
+                               uint64_t* n_mismatch, double* max_abs_diff);
+/* calibration of the box: kind 0/1 = MFMA-only loop 16x16x32 / 32x32x16 f16 (TFLOP/s), 2 = float4 copy (TB/s) */
+VP_API int vp_dbg_peak(int32_t device_id, int32_t kind, double* result);
+
+
 #ifdef __cplusplus
 }
 #endif

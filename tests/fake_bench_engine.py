@@ -10,6 +10,9 @@ FAMS = ['gemm_proj', 'gemm_fc1', 'gemm_qkv', 'gemm_patch', 'gemm_deconv', 'gemm_
 class FakeEngine:
     K = 5
 
+    LOG = []          # per process: ('infer', sync) / 'synchronize' in call order, shared by every FakeEngine of the process (the
+                      # host-sync test of tests/test_parallel_cpu.py interleaves it with the collectives)
+
     def __init__(self):
         self.calls = 0
 
@@ -21,11 +24,12 @@ class FakeEngine:
 
     def infer_device(self, d_crops, d_out, sync=True):
         self.calls += 1
+        FakeEngine.LOG.append(('infer', bool(sync)))
         d_out.copy_(self.expected(d_crops))
         return d_out
 
     def synchronize(self):
-        pass
+        FakeEngine.LOG.append('synchronize')
 
     def close(self):
         pass

@@ -14,8 +14,9 @@ cv2 functions are on the path and get a real implementation in the stub:
   OpenCV's float32 ``getGaussianKernel`` weights (an implementation independent of
   ``oracle/vitpose_cpu.gaussian_blur``; PARITY UNPINNED vs the real OpenCV binary),
 * ``cv2.resize`` -> identity when the crop is already 256x192; for the caller-level golden
-  (``frame_inference.npz``, crops of arbitrary size) the repo's own restatement of OpenCV's 8-bit
-  INTER_LINEAR (``easy_vitpose_amd.cropprep.resize_linear_u8``) -- the resize boundary stays
+  (``frame_inference.npz``, crops of arbitrary size) the ORACLE's plain-C restatement of OpenCV's 8-bit
+  INTER_LINEAR (``oracle/resize_ref.c`` through ``oracle.resize_ref.resize_linear_u8``; no golden depends on
+  product code -- the product's ``cropprep.resize_linear_u8`` and the device kernel are TESTED against it) -- the resize boundary stays
   PARITY UNPINNED, the golden pins everything around it (box padding/clipping, ``pad_image``,
   the per-box loop, the offset arithmetic, the key -> id mapping).
 
@@ -86,7 +87,7 @@ def _install_stubs():
     def resize(img, dsize, interpolation=None):
         if (img.shape[1], img.shape[0]) == tuple(dsize):
             return img
-        from easy_vitpose_amd.cropprep import resize_linear_u8
+        from oracle.resize_ref import resize_linear_u8     # the checker's C restatement, never the product's resize
         assert img.dtype == np.uint8
         return resize_linear_u8(np.ascontiguousarray(img), list(dsize))
 

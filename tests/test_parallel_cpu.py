@@ -102,6 +102,69 @@ def _bench_worker(rank, world, port, n_frame, q):
         dist.destroy_process_group()
 
 
+def _order_worker(rank, world, port, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        log = FakeEngine.LOG
+        real_ag, real_bar = dist.all_gather_into_tensor, dist.barrier
+
+        def ag(*a, **k):
+            log.append('all_gather')
+            return real_ag(*a, **k)
+
+        def bar(*a, **k):
+            log.append('barrier')
+            return real_bar(*a, **k)
+        dist.all_gather_into_tensor, dist.barrier = ag, bar      # ShardedPose and Harness both call through the module
+        B, K = 3, FakeEngine.K
+        H = bench.Harness(FakeEngine(), torch.zeros((B, 6, 4, 3), dtype=torch.uint8), torch.zeros((B, K, 3)), torch.zeros((world * B, K, 3)), dist,
+                          device_sync=lambda: log.append('device_sync'))
+        del log[:]
+        for _ in range(3):
+            H.step()
+        weak = list(log)
+        del log[:]
+        frame = _frame_crops(7)
+        bench.strong_scaling_config4(world, rank, torch.device('cpu'), 'fp16', steps=3, warmup=0, n_total=7,
+                                     engine_factory=lambda per, lo, hi: (FakeEngine(), frame[lo:hi].clone(), FakeEngine.K), dist=dist,
+                                     device_sync=lambda: log.append('device_sync'))
+        q.put((rank, weak, list(log)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_distributed_step_never_blocks_the_host_between_inference_and_collective():
+    """the all-gather is enqueued behind the keypoints on the device's stream -- no host synchronisation between the
+    inference call and the collective (bench.py's distributed step used to pass sync=True).  The fake engine and the
+    patched collectives record the host-side call order at world size 2: inside a weak-scaling step and inside a strong-scaled frame
+    every inference call is un-synchronised and is followed DIRECTLY by the all-gather; the host blocks only in the fences."""
+    world = 2
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_order_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    blocking = ('synchronize', 'device_sync', 'barrier')
+    for rank, weak, strong in res:
+        assert weak == [('infer', False), 'all_gather'] * 3, f'rank {rank}: weak-scaling step order {weak}'
+        # the strong-scaled frame loop: 3 frames of [infer, all_gather] back to back, then the closing fence and the timing exchange
+        fence = ['synchronize', 'device_sync', 'barrier']
+        assert strong[:3] == fence and strong[9:12] == fence, f'rank {rank}: opening / closing fence {strong}'
+        frames = strong[3:9]
+        assert frames == [('infer', False), 'all_gather'] * 3, f'rank {rank}: strong-scaling frame order {strong}'
+        assert not any(e in blocking for e in frames), f'rank {rank}: the host blocked inside the frame loop: {strong}'
+
+
 @pytest.mark.parametrize('n_frame', [7, 64, 1])
 def test_bench_multi_rank_code_path_with_fake_engine(n_frame):
     """bench.py's N > 1 code -- the weak-scaling Harness (step = local inference + all-gather, barrier-fenced timed loop, max over

@@ -1,7 +1,7 @@
 #!/bin/bash
-# the other BASELINE configurations on one GPU (round 5): one JSON line each -> gpurun_out/r5h/
+# the other BASELINE configurations on one GPU: one JSON line each -> gpurun_out/configs/ (summaries: profiles/bench_other_configs_rN.txt)
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
-OUT=$ROOT/gpurun_out/r5h; mkdir -p $OUT
+OUT=$ROOT/gpurun_out/configs; mkdir -p $OUT
 B="python $ROOT/bench.py --steps 40 --warmup 8 --no-cpu-baseline --no-host-path --no-clock"
 run() { tag=$1; shift; timeout 300 $B "$@" > $OUT/$tag.json 2> $OUT/$tag.err || echo "FAILED $tag" >> $OUT/failed.txt; }
 run s_coco_256 --variant s

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Small / mid batches on the PRODUCT build (round 5): the batch ladder in situ (tools/small_sweep.py: ms per step + us per launch of the encoder GEMM families + the kernels
 # the rule picked), the bench lines of the 8-crop share of BASELINE configs[3] and of single crops, hipGraph replay against eager launches.  -> gpurun_out/small_batch/
-# (profiles/small_batch_r5.txt holds the outputs of this script and of the exploratory sweeps that led to the rule; rocprofv3 of the same paths: tools/run_r5_smallprof.sh)
+# (profiles/small_batch_rN.txt hold the outputs of this script and of the exploratory sweeps that led to the rule; rocprofv3 of the same paths: tools/profile.sh small)
 cd ${GRAFT_REPO_ROOT:-/root/repo}
 OUT=gpurun_out/small_batch; mkdir -p $OUT
 VP_HIP_LIB=$PWD/easy_vitpose_amd/_lib/libvitpose_hip.so timeout 300 python tools/small_sweep.py --iters 100 --sets 'default=' \
@@ -12,4 +12,9 @@ for cfg in "--variant l --dataset coco_25 --batch 8" "--variant l --dataset coco
   echo -n "graph  $cfg: "; one timeout 100 $B $cfg
   echo -n "eager  $cfg: "; VP_GRAPH=0 one timeout 100 $B $cfg
 done > $OUT/bench_lines.txt 2>&1
-tail -3 $OUT/ladder.txt; cat $OUT/bench_lines.txt
+# the stream-ordered entry: launches on the caller's stream (default at <= 16 crops) against the event-fenced path, same box
+for cfg in "--variant l --dataset coco_25 --batch 8" "--variant b --batch 1"; do
+  echo -n "caller-stream  $cfg: "; one timeout 60 $B $cfg
+  echo -n "event-fenced   $cfg: "; VP_CALLER_STREAM=0 one timeout 60 $B $cfg
+done > $OUT/callerstream.txt 2>&1
+tail -3 $OUT/ladder.txt; cat $OUT/bench_lines.txt $OUT/callerstream.txt
