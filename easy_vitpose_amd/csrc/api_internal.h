@@ -109,6 +109,12 @@ struct vp_ctx {
                                       // ln_merge, bit-identical.  Measured (profiles/fold_stats_r3.txt): -7...-12 % per step at 1-8 crops, +0...+20 % at
                                       // 16-48 (every column tile merges its rows again): threshold 8.  VP_FOLD_STATS=n moves it (0 = always ln_finalize).
                                       // Round 2 merged per LANE in the epilogue (16 x redundant): slower than ln_finalize even at 8 crops (3.89 vs 2.97 ms).
+    // split-K for the residual GEMMs of small batches (round 6; tile_rules.hip pick_splitk, gemm.hip EPI_PARTIAL, elementwise.hip splitk_reduce_kernel): fp32 partial
+    // products [S][M][D] of up to splitk_rows token rows.  VP_SPLITK=0 switches it off (the parity test flips it); VP_SPLITK="fc2:S:variant,proj:S:variant" overrides the rule.
+    float* splitk_ws = nullptr;
+    size_t splitk_rows = 0;
+    bool splitk_on = true;
+    int splitk_force[2][2] = {{0, 0}, {0, 0}};   // [0 = proj, 1 = fc2][S, variant]; S = 0: the rule decides
     hipEvent_t ev_in = nullptr, ev_out = nullptr;   // vp_infer_device_stream: ordering against the caller's stream
     // vp_infer_device_stream at small batches (round 5): the launches go onto the CALLER's stream (c->stream points at it for the duration of that call) instead of
     // being fenced against it with two cross-stream events per call (~0.1 ms at 1-16 crops).  The handle's workspaces are then used from more than one stream over
@@ -214,6 +220,10 @@ struct G8Pick { int variant, bm, bn; long tiles; };
 G8Pick pick_gemm8_tile(int M, int N, bool wide, int bm192_mask, long min_tiles, bool extended);
 struct Tile2Pick { int variant, group_m; };
 Tile2Pick pick_gemm2_tile(int epi, int M, int N, int K);
+// split-K of a residual GEMM (attn.proj, mlp.fc2) at small batches: S k ranges on tile configuration `variant` (S = 1: no split)
+struct SplitKPick { int S, variant; };
+SplitKPick pick_splitk(int M, int N, int K);
+constexpr int SPLITK_MAX_S = 8, SPLITK_MAX_CROPS = 32;
 
 // ---- vitpose_api.hip: one GEMM of the path through the tile rules (also what the vp_dbg_gemm* taps launch)
 int gemm(vp_ctx* c, int fam, int epi, const uint16_t* A, const uint16_t* W, const float* bias, void* out,

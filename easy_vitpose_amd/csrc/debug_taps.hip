@@ -452,7 +452,21 @@ VP_API int vp_dbg_gemm_case(int32_t device, int32_t dtype, int32_t epi, int32_t 
     dOut = o;
     hipMemset(dOut, 0xff, out_bytes);
     g.out = dOut;
-    hipError_t e = vp::gemm_launch(c->dtype, epi, g, nullptr);
+    const int splitk = (flags >> 8) & 15;   // epi 6 only: S partial products (EPI_PARTIAL) + splitk_reduce_kernel instead of the one-launch residual epilogue
+    hipError_t e;
+    if (splitk > 1) {
+        if (epi != vp::EPI_BIAS_RESID_LN) return dbg_finish(c, fail(c, VP_ERR_INVALID, "split-K is a residual-GEMM path (epi 6)"));
+        float* ws = nullptr;
+        if ((r = dalloc(c, &ws, (size_t)splitk * MN))) return dbg_finish(c, r);
+        hipMemset(ws, 0xff, (size_t)splitk * MN * 4);
+        vp::GemmArgs p = g;
+        p.out = ws; p.aux = nullptr; p.bias = nullptr; p.stats_out = nullptr; p.plane = 0; p.splitk = splitk; p.persist = 0;
+        e = vp::gemm_launch(c->dtype, vp::EPI_PARTIAL, p, nullptr);
+        if (e == hipSuccess) e = vp::splitk_reduce_launch(c->dtype, ws, splitk, dB, dAux16, MN, dStats, M, N, nullptr);
+        dOut = dAux16;   // the reduction updates the residual planes in place
+    } else {
+        e = vp::gemm_launch(c->dtype, epi, g, nullptr);
+    }
     if (e == hipSuccess) e = hipDeviceSynchronize();
     if (e != hipSuccess) return dbg_finish(c, fail(c, VP_ERR_HIP, std::string("gemm case: ") + hipGetErrorString(e)));
     if (epi == vp::EPI_BIAS || epi == vp::EPI_BIAS_GELU) {

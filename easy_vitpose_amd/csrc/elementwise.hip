@@ -199,6 +199,14 @@ hipError_t layernorm_launch(int dtype, const float* x, const float* gamma, const
 }
 
 
+// sum over the 8 lanes of a DPP half-row (every lane receives it): quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror -- the sequence of gemm.hip::row8_sum
+__device__ __forceinline__ float row8_sum_dpp(float x) {
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xF, 0xF, true));
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x4E, 0xF, 0xF, true));
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x141, 0xF, 0xF, true));
+    return x;
+}
+
 // Fused-LayerNorm helper: the residual GEMMs leave, per token row and 64-column granule, (sum, M2 about the
 // granule mean).  Fold them in a FIXED order (deterministic, unlike atomics) into (mean, rstd) per row with the
 // pairwise-merge identity  M2 = sum_g [M2_g + 64 (mean_g - mean)^2]  -- no E[x^2] - mean^2 cancellation.
@@ -230,6 +238,76 @@ __global__ __launch_bounds__(64) void ln_finalize_kernel_t(const float* __restri
     float mean, rstd;
     ln_merge(v, TILES, inv_d, mean, rstd);
     *(float2*)(rowstat + 2 * (size_t)m) = float2{mean, rstd};
+}
+
+// Split-K reduction of a residual GEMM (round 6, small batches; gemm.hip EPI_PARTIAL): the S fp32 partial products of every output element are added in the
+// FIXED order s = 0 .. S - 1 (run-to-run deterministic; no atomics), then bias and the residual (hi + lo planes) exactly as the EPI_BIAS_RESID_LN epilogue adds
+// them -- st = sum + bias, v = st + (hi + lo) -- and the row leaves as the two planes + the (sum, centred M2) statistics of its 64-column granules (8 lanes of
+// 8 columns each, DPP adds in the epilogue's order).  One 8-column chunk per thread; every load of a thread is issued before the first add.
+template <class T, int SMAX>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, int S, const float* __restrict__ bias, uint16_t* __restrict__ x_hi,
+                                                            size_t plane, float* __restrict__ stats_out, int M, int N) {
+    const int cpr = N >> 3;
+    const size_t c = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const bool ok = c < (size_t)M * cpr;
+    const int m = ok ? (int)(c / cpr) : 0, ch = ok ? (int)(c - (size_t)m * cpr) : 0;
+    const size_t off = (size_t)m * N + ch * 8, slab = (size_t)M * N;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = 0.f;
+    if (ok) {
+        f32x4 p0[SMAX], p1[SMAX];
+#pragma unroll
+        for (int s = 0; s < SMAX; ++s)
+            if (s < S) {
+                p0[s] = *(const f32x4*)(part + s * slab + off);
+                p1[s] = *(const f32x4*)(part + s * slab + off + 4);
+            }
+        const u32x4 ra = *(const u32x4*)(x_hi + off), rb = *(const u32x4*)(x_hi + plane + off);
+        const f32x4 b0 = *(const f32x4*)(bias + ch * 8), b1 = *(const f32x4*)(bias + ch * 8 + 4);
+        f32x4 a0 = p0[0], a1 = p1[0];
+#pragma unroll
+        for (int s = 1; s < SMAX; ++s)
+            if (s < S) { a0 += p0[s]; a1 += p1[s]; }
+        a0 += b0; a1 += b1;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int sh = (e & 1) * 16;
+            const float r = from_bits<T>((uint16_t)(ra[e >> 1] >> sh)) + from_bits<T>((uint16_t)(rb[e >> 1] >> sh));
+            v[e] = (e < 4 ? a0[e] : a1[e - 4]) + r;
+        }
+        u32x4 oh, ol;
+#pragma unroll
+        for (int e = 0; e < 8; e += 2) { uint32_t h_, l_; split_planes2<T>(v[e], v[e + 1], h_, l_); oh[e >> 1] = h_; ol[e >> 1] = l_; }
+        *(u32x4*)(x_hi + off) = oh;
+        *(u32x4*)(x_hi + plane + off) = ol;
+    }
+    float s1 = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+    s1 = row8_sum_dpp(s1);
+    const float mg = s1 * (1.0f / 64.0f);
+    float s2 = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float d = v[e] - mg;
+        s2 = fmaf(d, d, s2);
+    }
+    s2 = row8_sum_dpp(s2);
+    if (ok && (ch & 7) == 0) *(float2*)(stats_out + ((size_t)m * (N >> 6) + (ch >> 3)) * 2) = float2{s1, s2};
+}
+
+hipError_t splitk_reduce_launch(int dtype, const float* partials, int S, const float* bias, uint16_t* x_hi, size_t plane, float* stats_out, int M, int N,
+                                hipStream_t s) {
+    if (S < 1 || S > 8 || N % 64 != 0 || M <= 0) return hipErrorInvalidValue;
+    const size_t chunks = (size_t)M * (N / 8);
+    const dim3 grid((unsigned)((chunks + 255) / 256)), block(256);
+    if (dtype == DT_F16) {
+        if (S <= 4) hipLaunchKernelGGL((splitk_reduce_kernel<F16, 4>), grid, block, 0, s, partials, S, bias, x_hi, plane, stats_out, M, N);
+        else hipLaunchKernelGGL((splitk_reduce_kernel<F16, 8>), grid, block, 0, s, partials, S, bias, x_hi, plane, stats_out, M, N);
+    } else {
+        if (S <= 4) hipLaunchKernelGGL((splitk_reduce_kernel<BF16, 4>), grid, block, 0, s, partials, S, bias, x_hi, plane, stats_out, M, N);
+        else hipLaunchKernelGGL((splitk_reduce_kernel<BF16, 8>), grid, block, 0, s, partials, S, bias, x_hi, plane, stats_out, M, N);
+    }
+    return hipGetLastError();
 }
 
 hipError_t ln_finalize_launch(const float* partials, float* rowstat, int M, int tiles, int D, hipStream_t s) {

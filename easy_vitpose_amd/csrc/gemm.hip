@@ -158,11 +158,17 @@ __global__ __launch_bounds__(C::NT, 2) void gemm_kernel(GemmArgs g) {
     // deconv: the four output parities of a tile are four CONSECUTIVE logical blocks (they read the same input rows, shifted by a tap): with
     // the XCD remap they run side by side on one XCD and share those rows in its L2 (parity on blockIdx.y ran all tiles of parity 0
     // first: every parity fetched the activations again)
-    int bid, parity = 0;
+    int bid, parity = 0, split = 0;
     if (AMODE == A_DECONV && g.parity_fast) {
         const int lb = xcd_remap(blockIdx.x, tiles_m * tiles_n * 4);
         parity = lb & 3;
         bid = lb >> 2;
+    } else if (EPI_ == EPI_PARTIAL) {
+        // split-K: logical block = split * tiles + tile, so that the contiguous range an XCD owns is (mostly) ONE k range of neighbouring tiles -- they share
+        // operand panels in its L2; the S workgroups of a tile share nothing but the output region
+        const int lb = xcd_remap(blockIdx.x, tiles_m * tiles_n * g.splitk);
+        split = lb / (tiles_m * tiles_n);
+        bid = lb - split * (tiles_m * tiles_n);
     } else {
         bid = xcd_remap(blockIdx.x, tiles_m * tiles_n);
         if (AMODE == A_DECONV) parity = blockIdx.y;
@@ -182,6 +188,8 @@ __global__ __launch_bounds__(C::NT, 2) void gemm_kernel(GemmArgs g) {
     }
     const int n0 = tn * C::BN, m0 = tm * C::BM;
     const int K = g.K;
+    const int klen = (EPI_ == EPI_PARTIAL) ? K / g.splitk : K;   // this workgroup's k range: [kbase, kbase + klen)
+    const int kbase = (EPI_ == EPI_PARTIAL) ? split * klen : 0;
     if constexpr (LN_PROD) {
         // experiment (tools build, VP_PROJ_STAGGER = 1000 mode + n): of the first round of workgroups (two per CU, all started together) the SECOND
         // one of every CU starts n x 1024 cycles late, so that one workgroup of a CU is in its HBM-bound epilogue while the other runs its K-loop.
@@ -229,7 +237,7 @@ __global__ __launch_bounds__(C::NT, 2) void gemm_kernel(GemmArgs g) {
     }
     auto stage = [&](int kt, int buf) {
         char* base = smem + buf * C::STAGE_BYTES + wave * 1024;
-        const int k0 = kt * C::BK;
+        const int k0 = kbase + kt * C::BK;
 #pragma unroll
         for (int p = 0; p < C::WP; ++p) glds16(wsrc[p] + k0, base + p * (C::NWAVES * 1024));
         if (AMODE == A_DENSE) {
@@ -265,7 +273,7 @@ __global__ __launch_bounds__(C::NT, 2) void gemm_kernel(GemmArgs g) {
 #pragma unroll
         for (int j = 0; j < C::TJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int nk = K / C::BK;
+    const int nk = klen / C::BK;
     if constexpr (C::PIPE == 2) {
         // Register double-buffered fragments over a STAGES-deep LDS ring (BK = 32, one 32-deep MFMA step
         // per barrier): while the MFMAs of tile kt run, the ds_reads of tile kt+1 (already landed and made
@@ -721,7 +729,7 @@ __global__ __launch_bounds__(C::NT, 2) void gemm_kernel(GemmArgs g) {
                 *(float2*)(g.stats_out + ((size_t)m * (g.N / 64) + (n >> 6)) * 2) = *(const float2*)(statbuf + t * 2);
         }
     } else if constexpr (EPI != EPI_HEATMAP && !C::DIRECT) {
-        constexpr int ES = (EPI == EPI_BIAS_RESID || EPI == EPI_POS) ? 4 : 2;   // bytes per staged element
+        constexpr int ES = (EPI == EPI_BIAS_RESID || EPI == EPI_POS || EPI == EPI_PARTIAL) ? 4 : 2;   // bytes per staged element
         constexpr int ROWBYTES = C::BN * ES + 16;                               // +16 B: conflict-free fragment writes
         constexpr int JP = epi_rows_per_pass<C, ES>();
         constexpr int CR = C::NWM * JP * 16;                                    // rows staged per pass
@@ -732,7 +740,7 @@ __global__ __launch_bounds__(C::NT, 2) void gemm_kernel(GemmArgs g) {
         f32x4 bias4[C::TI];
 #pragma unroll
         for (int i = 0; i < C::TI; ++i)
-            bias4[i] = (EPI == EPI_POS) ? f32x4{0.f, 0.f, 0.f, 0.f} : *(const f32x4*)(g.bias + n0 + wn * C::WN + i * 16 + fg * 4);
+            bias4[i] = (EPI == EPI_POS || EPI == EPI_PARTIAL) ? f32x4{0.f, 0.f, 0.f, 0.f} : *(const f32x4*)(g.bias + n0 + wn * C::WN + i * 16 + fg * 4);
         // fused LayerNorm, consumer side: per-row (mean, rstd) of this lane's TJ fragment rows
         constexpr bool LN_CONSUMER = (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU);
         const bool ln_in = LN_CONSUMER && (g.rowstat != nullptr || g.ln_part != nullptr);
@@ -772,7 +780,7 @@ __global__ __launch_bounds__(C::NT, 2) void gemm_kernel(GemmArgs g) {
             // this thread's output chunks of the pass: row offsets, and the fp32 residual / pos operand is
             // fetched NOW (coalesced 16 B per lane) so its latency overlaps the LDS staging below
             size_t orow_q[NCH];
-            f32x4 res[ES == 4 ? NCH : 1];
+            f32x4 res[(ES == 4 && EPI != EPI_PARTIAL) ? NCH : 1];
 #pragma unroll
             for (int q = 0; q < NCH; ++q) {
                 const int c = tid + q * C::NT;
@@ -788,7 +796,8 @@ __global__ __launch_bounds__(C::NT, 2) void gemm_kernel(GemmArgs g) {
                 } else {
                     orow_q[q] = (size_t)m * g.ldo;
                 }
-                if (ES == 4) {
+                if (EPI == EPI_PARTIAL) orow_q[q] += (size_t)split * g.M * g.ldo;   // partial slab of this k range
+                if (ES == 4 && EPI != EPI_PARTIAL) {
                     const size_t arow = (EPI == EPI_POS) ? (size_t)(m % 192) * g.ldo : orow_q[q];
                     res[q] = *(const f32x4*)(g.aux + arow + n);
                 }
@@ -848,6 +857,8 @@ __global__ __launch_bounds__(C::NT, 2) void gemm_kernel(GemmArgs g) {
                         }
                         if (n + 8 <= g.N) *(u32x4*)dst = v;
                         else *(u32x2*)dst = u32x2{v[0], v[1]};   // N % 8 == 4 tail (N % 4 == 0 is required)
+                    } else if (EPI == EPI_PARTIAL) {
+                        *(f32x4*)((float*)g.out + orow_q[q] + n) = *(const f32x4*)src;
                     } else {
                         *(f32x4*)((float*)g.out + orow_q[q] + n) = *(const f32x4*)src + res[q];
                     }
@@ -1252,7 +1263,10 @@ static hipError_t launch(const GemmArgs& a, hipStream_t s) {
     g.w_parity_stride = (size_t)a.w_rows * a.K;
     if ((size_t)tiles_n * C::BN > (size_t)a.w_rows) return hipErrorInvalidValue;   // weight rows are padded at upload
     const int tiles = ((a.M + C::BM - 1) / C::BM) * tiles_n;
-    dim3 grid(AMODE == A_DECONV && a.parity_fast ? tiles * 4 : tiles, AMODE == A_DECONV && !a.parity_fast ? 4 : 1);
+    if constexpr (EPI == EPI_PARTIAL) {
+        if (a.splitk < 1 || a.K % (a.splitk * C::BK * (C::PIPE == 6 ? 2 : 1)) != 0 || a.ldo != a.N || a.N % 4 != 0 || C::DIRECT || C::PIPE == 2 || C::PIPE == 3) return hipErrorInvalidValue;
+    }
+    dim3 grid(AMODE == A_DECONV && a.parity_fast ? tiles * 4 : (EPI == EPI_PARTIAL ? tiles * a.splitk : tiles), AMODE == A_DECONV && !a.parity_fast ? 4 : 1);
     if (a.desc)
         snprintf(a.desc, a.desc_cap, "gemm_kernel<%s, %d, %d, TileCfg<%d, %d, %d, %d, %d, %d, %d, %d>>", std::is_same<T, F16>::value ? "F16" : "BF16", EPI,
                  AMODE, C::BM, C::BN, C::BK, C::WM, C::WN, C::STAGES, C::PIPE, C::DIRECT);
@@ -1304,6 +1318,21 @@ static hipError_t by_variant(const GemmArgs& a, hipStream_t s) {
     return hipErrorInvalidValue;
 }
 
+// split-K partial products (EPI_PARTIAL): the tiles the small-batch rule of tile_rules.hip may pick for them
+template <class T>
+static hipError_t by_variant_partial(const GemmArgs& a, hipStream_t s) {
+    switch (a.variant) {
+        case 1: return launch<T, EPI_PARTIAL, A_DENSE, Cfg1>(a, s);
+        case 11: return launch<T, EPI_PARTIAL, A_DENSE, Cfg11>(a, s);
+        case 12: return launch<T, EPI_PARTIAL, A_DENSE, Cfg12>(a, s);
+        case 15: return launch<T, EPI_PARTIAL, A_DENSE, Cfg15>(a, s);
+        case 20: return launch<T, EPI_PARTIAL, A_DENSE, Cfg20>(a, s);
+        case 30: return launch<T, EPI_PARTIAL, A_DENSE, Cfg30>(a, s);
+        case 31: return launch<T, EPI_PARTIAL, A_DENSE, Cfg31>(a, s);
+    }
+    return hipErrorInvalidValue;
+}
+
 template <class T>
 static hipError_t dispatch(int epi, const GemmArgs& a, hipStream_t s) {
     switch (epi) {
@@ -1315,6 +1344,7 @@ static hipError_t dispatch(int epi, const GemmArgs& a, hipStream_t s) {
         case EPI_HEATMAP: return by_variant<T, EPI_HEATMAP, A_DENSE>(a, s);
         case EPI_BIAS_RESID_LN: return by_variant<T, EPI_BIAS_RESID_LN, A_DENSE>(a, s);
         case EPI_POS_LN: return by_variant<T, EPI_POS_LN, A_DENSE>(a, s);
+        case EPI_PARTIAL: return by_variant_partial<T>(a, s);
         case EPI_DECONV_FINAL:   // one tile configuration: 256 x 256 (all channels of a pixel in one tile)
             if (a.variant != 3 || a.N != Cfg3::BN || !a.W2 || !a.bias2 || !a.out2 || a.Kp <= 0) return hipErrorInvalidValue;
             return launch<T, EPI_DECONV_FINAL, A_DECONV, Cfg3>(a, s);

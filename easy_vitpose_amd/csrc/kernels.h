@@ -35,6 +35,9 @@ enum GemmEpi {
                             // fp32 NCHW heatmaps at out2 (256 x 256 tile only: N == 256, variant 3)
     EPI_QKV_ATTN = 9,       // gemm8.hip, 192 x 256 tiles only (round 5): attn.qkv of ONE crop x ONE head of head dim 80 (W = head-major [q | k | v | 16 zero rows],
                             // N = heads * 256) with the LayerNorm-consumer fold, q / k / v handed to the attention core through LDS; out = y [M, K] 16-bit
+    EPI_PARTIAL = 10,       // split-K (round 6, small batches): workgroup (split s, tile) multiplies k in [s K / S, (s + 1) K / S) and writes its fp32 partial tile to
+                            // out[s][M][ldo] -- no bias, no residual; splitk_reduce_launch adds the S partials in the fixed order s = 0 .. S - 1 (deterministic), then
+                            // bias + residual planes, and writes planes + row statistics exactly like the EPI_BIAS_RESID_LN epilogue
 };
 enum GemmAMode { A_DENSE = 0, A_DECONV = 1 };
 
@@ -92,6 +95,7 @@ struct GemmArgs {
     // row-major [w_rows, K] (at `W`) + one fp32 scale per output channel; EPI_BIAS_GELU writes its output as MXFP8 (codes at `out`, K of the
     // consumer = ldo, scales at out_scales)
     float attn_scale_log2e;   // EPI_QKV_ATTN: head_dim^-0.5 * log2(e)
+    int splitk;        // EPI_PARTIAL: number of k ranges S (K % (S * BK) == 0; grid = tiles * S)
     int parity_fast;   // deconv: 1 = the four output parities of a tile are consecutive logical blocks (same XCD, shared input rows); 0 = parity on blockIdx.y
     const uint8_t* a_scales;
     const float* w_scale;
@@ -122,6 +126,11 @@ hipError_t fill_random16(int dtype, uint16_t* p, size_t n, uint32_t seed, hipStr
 
 // partial row statistics [M][tiles][2] (sum, centred M2 per 64-column granule) -> rowstat [M][2] (mean, rstd), LayerNorm eps 1e-6
 hipError_t ln_finalize_launch(const float* partials, float* rowstat, int M, int tiles, int D, hipStream_t s);
+// split-K reduction of a residual GEMM (EPI_PARTIAL partials [S][M][N] fp32): x = ((p_0 + p_1) + ... + p_{S-1}) + bias + (x_hi + x_lo), written back as
+// the two residual planes (in place: hi at x_hi, lo `plane` elements behind) + the partial row statistics [M][N/64][2] the LayerNorm consumers fold --
+// the arithmetic of the EPI_BIAS_RESID_LN epilogue behind a fixed-order sum of the partials.  N % 64 == 0.
+hipError_t splitk_reduce_launch(int dtype, const float* partials, int S, const float* bias, uint16_t* x_hi, size_t plane, float* stats_out, int M, int N,
+                                hipStream_t s);
 
 // fp8_probe.hip (parity tap of BASELINE config 5): rows of A [M,K] / W [N,K] -> e4m3 codes (x / scale[row]), out = scaled product
 // through v_mfma_f32_16x16x128_f8f6f4

@@ -89,6 +89,12 @@ Tile2Pick pick_gemm2_tile(int epi, int M, int N, int K) {
     return tp;
 }
 
+// Split-K of a residual GEMM at small batches.  (Round 6; filled in from the in-situ sweep: profiles/small_batch_r6.txt.)
+SplitKPick pick_splitk(int M, int N, int K) {
+    (void)M; (void)N; (void)K;
+    return {1, 0};
+}
+
 }  // namespace vpi
 
 extern "C" {

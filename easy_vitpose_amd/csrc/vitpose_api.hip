@@ -6,7 +6,7 @@
 using namespace vpi;
 
 #ifndef VP_GRAPH_NULL_DEFAULT
-#define VP_GRAPH_NULL_DEFAULT 0
+#define VP_GRAPH_NULL_DEFAULT 1
 #endif
 
 namespace vpi {
@@ -140,6 +140,26 @@ int gemm(vp_ctx* c, int fam, int epi, const uint16_t* A, const uint16_t* W, cons
     char desc[192];
     desc[0] = 0;
     g.desc = desc; g.desc_cap = (int)sizeof(desc);   // the launch code names the kernel it resolved to (one snprintf per GEMM launch: vp_profile_kernel reports the LAST launch)
+    // small batches: a residual GEMM as S partial products over k ranges + a fixed-order reduction (tile_rules.hip pick_splitk)
+    if (epi == vp::EPI_BIAS_RESID_LN && c->splitk_ws && (size_t)M <= c->splitk_rows && c->gemm_variant[fam] < 0 && !(g.variant >= 16 && g.variant <= 18) &&
+        out == (void*)aux && (fam == VP_PROF_GEMM_FC2 || fam == VP_PROF_GEMM_PROJ)) {
+        const int which = fam == VP_PROF_GEMM_FC2 ? 1 : 0;
+        SplitKPick sk = pick_splitk(M, N, K);
+        if (c->splitk_force[which][0] > 0) sk = {c->splitk_force[which][0], c->splitk_force[which][1]};
+        if (sk.S > 1 && sk.S <= SPLITK_MAX_S && K % (sk.S * 128) == 0) {
+            vp::GemmArgs p = g;
+            p.out = c->splitk_ws; p.aux = nullptr; p.bias = nullptr; p.stats_out = nullptr; p.plane = 0;
+            p.variant = sk.variant; p.group_m = 0; p.splitk = sk.S; p.ldo = N; p.persist = 0;
+            LAUNCH(c, fam, flops, bytes, vp::gemm_launch(c->dtype, vp::EPI_PARTIAL, p, c->stream));   // (flops / bytes stay the algorithmic figures of the GEMM; the partials' round trip is overhead)
+            if (desc[0]) {
+                char d2[224];
+                snprintf(d2, sizeof(d2), "%s x split-K %d + splitk_reduce_kernel", desc, sk.S);
+                if (c->kernel_desc[fam] != d2) c->kernel_desc[fam] = d2;
+            }
+            LAUNCH(c, fam, 0.0, 0.0, vp::splitk_reduce_launch(c->dtype, c->splitk_ws, sk.S, bias, (uint16_t*)out, g.plane, g.stats_out, M, N, c->stream));
+            return VP_OK;
+        }
+    }
     LAUNCH(c, fam, flops, bytes, vp::gemm_launch(c->dtype, epi, g, c->stream));
     if (desc[0] && c->kernel_desc[fam] != desc) c->kernel_desc[fam] = desc;
     return VP_OK;
@@ -500,6 +520,22 @@ int vp_create(vp_handle* out, const vp_config* cfg) {
     if (const char* f = getenv("VP_DECONV_PARITY_FAST")) c->deconv_parity_fast = atoi(f) != 0;
     if (const char* f = getenv("VP_G8_COST")) c->g8_cost_model = atoi(f) != 0;
     if (const char* f = getenv("VP_G8_BM192")) c->g8_bm192 = atoi(f);   // mask: 1 = residual GEMMs, 2 = wide GEMMs may take the 192 x 256 tile of the 8-phase kernel (0: never)
+    if (const char* f = getenv("VP_SPLITK")) {   // 0 = off; "fc2:S:variant,proj:S:variant" = override the rule (measurement sweeps)
+        if (!strchr(f, ':')) c->splitk_on = atoi(f) != 0;
+        else {
+            const char* t = f;
+            while (*t) {
+                const int which = !strncmp(t, "fc2:", 4) ? 1 : !strncmp(t, "proj:", 5) ? 0 : -1;
+                if (which < 0) break;
+                t = strchr(t, ':') + 1;
+                int S = 0, v = 0, used = 0;
+                if (sscanf(t, "%d:%d%n", &S, &v, &used) != 2) break;
+                c->splitk_force[which][0] = S; c->splitk_force[which][1] = v;
+                t += used;
+                if (*t == ',') ++t;
+            }
+        }
+    }
     if (const char* f = getenv("VP_GEMM8")) c->gemm8_mask = atoi(f);   // which GEMMs may take the 8-phase kernel (1 fc2, 2 fc1, 4 qkv, 8 proj; 0 = the 2-phase kernels everywhere)
 #ifdef VP_TOOLS   // development switches of the measurement build (tools/)
     if (const char* f = getenv("VP_BLOCKED_HID")) c->blocked_hid = atoi(f) != 0;
@@ -533,6 +569,10 @@ int vp_create(vp_handle* out, const vp_config* cfg) {
     if ((rc = dalloc(c, &c->d2, B * 3072 * 256))) return bail(rc);
     if ((rc = dalloc(c, &c->hm, B * c->Kp * 3072))) return bail(rc);
     if ((rc = dalloc(c, &c->kp, B * c->Kp * 3))) return bail(rc);
+    if (c->fuse_ln && !c->fp8 && c->splitk_on) {
+        c->splitk_rows = (size_t)std::min<int>(c->maxb, SPLITK_MAX_CROPS) * 192;
+        if ((rc = dalloc(c, &c->splitk_ws, (size_t)SPLITK_MAX_S * c->splitk_rows * D))) return bail(rc);
+    }
     if ((rc = dalloc(c, &c->zero, (size_t)256))) return bail(rc);
     if (hipMemset(c->zero, 0, 512) != hipSuccess) { c->err = "hipMemset"; return bail(VP_ERR_HIP); }
     *out = c;

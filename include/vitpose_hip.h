@@ -259,7 +259,8 @@ VP_API int vp_dbg_crop_prep(int32_t device_id, const uint8_t* frame, int32_t fh,
                             int32_t n, uint8_t* out);
 /* one launch of a production GEMM configuration on HOST data (layouts built / undone inside): variant = tile configuration (gemm.hip Cfg id;
  * 16 / 17 / 18 = the 8-phase kernel of gemm8.hip with 256x256 / 256x192 / 192x256 tiles); flags: 1 persistent workgroups, 2 64x64-blocked output,
- * 4 64x64-blocked A operand, 8 reversed tile walk, 16 LayerNorm-consumer fold; epi 0-3, 5 (final 1x1 conv with hi+lo
+ * 4 64x64-blocked A operand, 8 reversed tile walk, 16 LayerNorm-consumer fold, bits 8-11 = S > 1: split-K (epi 6 only: S partial products over k ranges +
+ * the fixed-order reduction kernel, the small-batch path of attn.proj / mlp.fc2); epi 0-3, 5 (final 1x1 conv with hi+lo
  * weights -> heatmaps [M/3072, N, 3072]), 6, 7; rowstat [M,2] + ln_s [N] = LayerNorm-consumer fold; stats [M, N/64, 2] (epi 6 / 7) */
 VP_API int vp_dbg_gemm_case(int32_t device_id, int32_t dtype, int32_t epi, int32_t variant, int32_t group_m, int32_t flags,
                             int32_t M, int32_t N, int32_t K, const float* A, const float* W, const float* bias, const float* aux,

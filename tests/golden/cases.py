@@ -113,6 +113,53 @@ def fullbatch_crops(n: int):
     return out
 
 
+def content_plan():
+    """(variant, dataset, crops) of the CONTENT-DEPENDENT goldens (round 6): 64 crops x every BASELINE model (ascending keypoint count, see fullbatch_plan)."""
+    return [('s', 'coco', 64), ('b', 'coco', 64), ('b', 'ap10k', 64), ('l', 'coco_25', 64), ('h', 'wholebody', 64)]
+
+
+def content_crops(n: int, seed: int = 61):
+    """Crops whose CONTENT places the keypoints: one red, one green and one blue Gaussian blob (sigma 8-12 px, amplitude 150-200 on its colour
+    channel) at seeded positions on a dark noisy background.  Returns (uint8 crops [n, 256, 192, 3], blobs [n, 3, 3] = (cy, cx, sigma) in crop
+    pixels per colour).  With the content read-out (`content_state_dict`) joint k peaks at the centre of blob k % 3."""
+    rng = np.random.default_rng(seed)
+    H, W = 256, 192
+    yy, xx = np.mgrid[0:H, 0:W].astype(np.float32)
+    out = np.empty((n, H, W, 3), np.uint8)
+    blobs = np.empty((n, 3, 3), np.float64)
+    for i in range(n):
+        img = rng.uniform(15, 45, size=(H, W, 3)).astype(np.float32)
+        for c in range(3):
+            cy, cx = rng.uniform(20, H - 20), rng.uniform(20, W - 20)
+            s = rng.uniform(8, 12)
+            g = np.exp(-((yy - cy) ** 2 + (xx - cx) ** 2) / (2 * s * s))
+            img[..., c] += g * np.float32(rng.uniform(150, 200))
+            blobs[i, c] = (cy, cx, s)
+        out[i] = np.clip(img, 0, 255).astype(np.uint8)
+    return out, blobs
+
+
+def content_state_dict(variant: str, dataset: str):
+    """The CONTENT-DEPENDENT parity checkpoint: the seeded random checkpoint of `synthetic_state_dict(shape, 0)` -- every
+    tensor of the backbone and of both deconvs random -- with `keypoint_head.final_layer` replaced by a ridge fit (tests/golden/
+    fit_content_readout.py, run once in the build container with the CPU oracle; the fitted [K, 256] weights + [K] bias are the fixture
+    tests/golden/content_readout_<variant>_<dataset>.npz) that makes joint k's heatmap a blob at the centre of colour blob k % 3 of the crop.
+    The read-out is linear on the 256 head features, which are functions of the crop THROUGH all L encoder blocks: unlike the `peaked`
+    checkpoint (positions designed into pos_embed / final_layer, content only modulating the peak height), an encoder error here moves
+    coordinates."""
+    import os
+    from easy_vitpose_amd.configs import model_shape
+    from easy_vitpose_amd.synth import synthetic_state_dict
+    shp = model_shape(variant, dataset)
+    sd = synthetic_state_dict(shp, 0)
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), f'content_readout_{variant}_{dataset}.npz'))
+    K = shp.num_keypoints
+    assert z['weight'].shape == (K, 256) and z['bias'].shape == (K,)
+    sd['keypoint_head.final_layer.weight'] = np.ascontiguousarray(z['weight'].reshape(K, 256, 1, 1).astype(np.float32))
+    sd['keypoint_head.final_layer.bias'] = np.ascontiguousarray(z['bias'].astype(np.float32))
+    return shp, sd
+
+
 def tracker_sequence():
     """Detections [n, 5] (x1, y1, x2, y2, score) per frame for the tracker golden: three people walking (one of them missed by
     the detector on two frames), a fourth entering at frame 6, two crossing paths, and detector-skipped (empty) frames as

@@ -2,7 +2,7 @@
 """Generate the golden fixtures by running THE REFERENCE ITSELF in this container.
 
     python tests/golden/make_golden.py            # writes tests/golden/*.npz
-    python tests/golden/make_golden.py --only=tracker,outlier     # sections: caller decode model tracker peaked outlier fullbatch
+    python tests/golden/make_golden.py --only=tracker,outlier     # sections: caller decode model tracker peaked outlier fullbatch content
 
 Runs only where ``/root/reference`` exists (the build container).  The reference
 package is imported read-only with ``sys.dont_write_bytecode`` and with empty stub
@@ -341,6 +341,33 @@ def main():
             print(f'full batch {variant}/{dataset}: {n} crops x {shp.num_keypoints} joints through the reference in {time.time() - t0:.0f} s, '
                   f'confidences {kps[..., 2].min():.3f} .. {kps[..., 2].max():.3f}', flush=True)
             np.savez_compressed(os.path.join(HERE, f'full_{variant}_{dataset}_{n}.npz'), variant=variant, dataset=dataset, n=n, keypoints=kps)
+
+    if want('content'):
+        # CONTENT-DEPENDENT checkpoint (round 6; cases.content_state_dict: random backbone + deconvs, ridge-fitted final layer stored as a
+        # fixture by fit_content_readout.py): the keypoint LOCATIONS are a function of the crop through all L blocks.  64 crops x every
+        # BASELINE model through the reference, crop by crop; the blob centres are stored beside the keypoints so that the tests can
+        # show the locations track the content.
+        import time
+        from cases import content_crops, content_plan, content_state_dict
+        for variant, dataset, n in content_plan():
+            shp, sd = content_state_dict(variant, dataset)
+            V = build_ref(VitInference, ViTPose, dyn_model_import, dataset, variant, sd)
+            crops, blobs = content_crops(n)
+            t0 = time.time()
+            with torch.no_grad():
+                kps = np.concatenate([V._inference_torch(crops[i]) for i in range(n)], 0).astype(np.float32)
+            # oracle-vs-reference on the first crops (the same check tests/test_oracle_golden.py repeats against the stored outputs)
+            from oracle import vitpose_cpu as O
+            sdt = O.to_torch_state_dict(sd)
+            okp = np.concatenate([O.inference_torch(sdt, shp.depth, shp.num_heads, crops[i]) for i in range(4)])
+            K = shp.num_keypoints
+            want_yx = np.stack([blobs[:, np.arange(K) % 3, 0], blobs[:, np.arange(K) % 3, 1]], -1)
+            loc = np.hypot(kps[..., 0] - want_yx[..., 0], kps[..., 1] - want_yx[..., 1])
+            print(f'content {variant}/{dataset}: {n} crops x {K} joints through the reference in {time.time() - t0:.0f} s, confidences '
+                  f'{kps[..., 2].min():.3f} .. {kps[..., 2].max():.3f}, distance to the blob centres median {np.median(loc):.2f} px / p90 '
+                  f'{np.percentile(loc, 90):.2f} px, oracle-vs-reference max|d| = {np.abs(okp - kps[:4]).max():.3e}', flush=True)
+            np.savez_compressed(os.path.join(HERE, f'full_content_{variant}_{dataset}.npz'), variant=variant, dataset=dataset, n=n, keypoints=kps,
+                                blobs=blobs.astype(np.float32))
 
 
 if __name__ == '__main__':

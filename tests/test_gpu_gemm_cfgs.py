@@ -114,6 +114,43 @@ def test_residual_gemm_configurations(operands, name, K, flags):
         assert np.array_equal(o, bo) and np.array_equal(st, bs), f'{name}: {label} differs from cfg11'
 
 
+@pytest.mark.parametrize('name,K,Dm,rows', [('fc2 ViTPose-L x 8', 4096, 1024, 192 * 8), ('fc2 ViTPose-B x 1', 3072, 768, 192), ('proj ViTPose-H x 4', 1280, 1280, 192 * 4),
+                                            ('fc2 ViTPose-S x 3', 1536, 384, 192 * 3)])
+def test_split_k_residual_gemm(name, K, Dm, rows):
+    """Round 6, small batches: a residual GEMM as S partial products over k ranges (gemm.hip EPI_PARTIAL) + the fixed-order reduction kernel
+    (elementwise.hip splitk_reduce_kernel).  Planes and granule statistics against fp64 at the tolerance of the one-launch epilogue; every (S, tile)
+    combination run-to-run BIT-IDENTICAL (the reduction adds the partials in the order s = 0 .. S - 1: no atomics); all tiles of one S agree bit for bit
+    (same k order inside a range, same reduction); against the unsplit kernel the planes differ only by the fp32 accumulation order."""
+    rng = np.random.default_rng(K + rows)
+    A = round_to((rng.standard_normal((rows, K)) * (1.0 if K == Dm else 0.5)).astype(np.float32), 'fp16')
+    W = round_to((rng.standard_normal((Dm, K)) * 0.03).astype(np.float32), 'fp16')
+    bias = (rng.standard_normal(Dm) * 0.1).astype(np.float32)
+    resid = (rng.standard_normal((rows, Dm)) * 2.0).astype(np.float32)
+    flags = 0 if K == Dm else AB
+    hi = round_to(resid, 'fp16')
+    x0 = hi.astype(np.float64) + round_to(resid - hi, 'fp16').astype(np.float64)
+    ref = A.astype(np.float64) @ W.astype(np.float64).T + bias + x0
+    base, _ = _case(6, 12, flags, A, W, bias, aux=resid, want_stats=True, group_m=0)
+    for S in (2, 4, 8):
+        if K % (S * 128):
+            continue
+        per_s = {}
+        for variant in (12, 1, 11, 15, 20, 30, 31):
+            o, st = _case(6, variant, flags | (S << 8), A, W, bias, aux=resid, want_stats=True, group_m=0)
+            o2, st2 = _case(6, variant, flags | (S << 8), A, W, bias, aux=resid, want_stats=True, group_m=0)
+            assert np.array_equal(o, o2) and np.array_equal(st, st2), f'{name}: split-K {S} on cfg{variant} is not run-to-run deterministic'
+            assert np.abs(o - ref).max() < 2e-5 * max(1.0, np.abs(ref).max()), f'{name} S={S} cfg{variant}: planes off by {np.abs(o - ref).max():.3e}'
+            g = o.astype(np.float64).reshape(rows, Dm // 64, 64)
+            assert np.abs(st[..., 0] - g.sum(-1)).max() < 2e-3, f'{name} S={S} cfg{variant}: granule sums'
+            m2 = ((g - g.mean(-1, keepdims=True)) ** 2).sum(-1)
+            assert np.abs(st[..., 1] - m2).max() < 2e-3 * max(1.0, m2.max()), f'{name} S={S} cfg{variant}: granule M2'
+            assert np.abs(o - base).max() < 4e-6 * max(1.0, np.abs(ref).max()), f'{name} S={S} cfg{variant}: further from the unsplit kernel than an accumulation order explains'
+            per_s[variant] = (o, st)
+        o0, s0 = per_s[12]
+        for variant, (o, st) in per_s.items():
+            assert np.array_equal(o, o0) and np.array_equal(st, s0), f'{name}: split-K {S} on cfg{variant} differs from cfg12'
+
+
 @pytest.mark.parametrize('K,rows', [(768, 192 * 136), (3072, 192 * 136), (768, 192 * 7)])
 def test_residual_gemm_192_row_tiles_across_tile_boundaries(K, rows):
     """The 8-phase kernel's 192 x 256 tile (X halves of 96 rows: uneven DMA piece counts per wave group, register-direct residual

@@ -233,6 +233,38 @@ def test_full_batch_against_the_reference_itself(golden_dir, variant, dataset, n
     assert dcf.max() < CONF_TOL
 
 
+def _content_cases():
+    from cases import content_plan
+    return content_plan()
+
+
+@pytest.mark.parametrize('variant,dataset,n', _content_cases(), ids=[f'{v}-{d}-{n}' for v, d, n in _content_cases()])
+def test_content_dependent_checkpoint_against_the_reference_itself(golden_dir, variant, dataset, n):
+    """the first end-to-end test in which an ENCODER error moves a coordinate.  Checkpoint = cases.content_state_dict (every tensor
+    of the backbone and of both deconvs seeded-random; `final_layer` ridge-fitted on the 256 head features, stored as a fixture) -- joint k's heatmap
+    peaks on colour blob k % 3 of the crop, so the keypoint locations are a function of the crop through all L blocks (tests/test_oracle_golden.py::
+    test_content_goldens_are_a_function_of_the_crop).  64 crops x every BASELINE model against the keypoints the REFERENCE produced crop by crop
+    (full_content_*.npz, make_golden.py --only=content): +-0.5 px and 1e-3 on EVERY joint, the north_star's tolerances."""
+    from cases import content_crops, content_state_dict
+    z = np.load(os.path.join(golden_dir, f'full_content_{variant}_{dataset}.npz'))
+    assert int(z['n']) == n
+    shp, sd = content_state_dict(variant, dataset)
+    crops, _ = content_crops(n)
+    eng = VitPoseHip(shp, sd, dtype='fp16', device_id=0, max_batch=n)
+    kp = eng.infer(crops)
+    kp8 = np.concatenate([eng.infer(crops[i:i + 8]) for i in (0, 8)])          # the small-batch kernels (split-K, one workgroup per tile) on the same crops
+    eng.close()
+    ref = z['keypoints']
+    assert kp.shape == ref.shape == (n, shp.num_keypoints, 3) and np.isfinite(kp).all()
+    for tag, got, want in (('one call', kp, ref), ('8-crop calls', kp8, ref[:16])):
+        dpx = np.abs(got[..., :2] - want[..., :2]).max(-1)
+        dcf = np.abs(got[..., 2] - want[..., 2])
+        print(f'[content {variant}/{dataset} x {len(got)}, {tag}, vs the reference] {dpx.size} joints: coordinate max err {dpx.max():.4f} px (mean {dpx.mean():.5f}), '
+              f'confidence max err {dcf.max():.3e} (rms {np.sqrt((dcf ** 2).mean()):.3e}), confidences {want[..., 2].min():.3f} .. {want[..., 2].max():.3f}')
+        assert dpx.max() < KP_TOL_PX, tag
+        assert dcf.max() < CONF_TOL, tag
+
+
 def test_noise_map_confidence_statistic_vitpose_h():
     """Random-weight heatmaps are full-scale noise (std 0.3, maxima ~1): with 16-bit operands the error at the arg-max is
     ~N(0, 3.3e-4) on the 32-block model, so 1e-3 is a 3-sigma event per joint and `every joint < 1e-3` is not a property of the

@@ -2,7 +2,9 @@
 """Small batches IN SITU (one GPU's share of a sharded frame: BASELINE configs[3] = ViTPose-L, 8 crops): ms per step of the whole hot path (hipGraph replay) and
 us per launch of the four encoder GEMM families for tile-configuration overrides (VP_GEMM_TUNE, measurement build), each checked for bit-identical keypoints against
 the default rule.  The isolated sweeps of rounds 2-3 (tools/gemm_small.py) ran with L2-resident weights; inside the step every layer's weights come from HBM.
-GPU box only.      python tools/small_sweep.py [--cases l:coco_25:8,...] [--sets name=tune;name=tune...]"""
+Round 6: a set may carry a split-K override of the residual GEMMs behind a '|' (VP_SPLITK, e.g. `sk=|fc2:4:20,proj:2:12`; `off=|0`); the family columns are us per LAYER
+(a split-K family is two launches: partial products + reduction).
+GPU box only.      python tools/small_sweep.py [--cases l:coco_25:8,...] [--sets name=tune[|splitk];name=tune...]"""
 import argparse
 import os
 import sys
@@ -48,9 +50,14 @@ for case in args.cases.split(','):
     sd = synthetic_state_dict(shp, 0)
     crops = torch.from_numpy(np.ascontiguousarray(synthetic_crops(n, 0, 'noise'))).cuda()
     out = torch.empty((n, shp.num_keypoints, 3), dtype=torch.float32, device='cuda')
-    print(f'# ViTPose-{variant.upper()} / {dataset}, {n} crops (M = {192 * n}, D = {shp.embed_dim}): ms per step (hipGraph replay, {args.iters} calls) | us per launch: qkv fc1 proj fc2 attention | kernels | keypoints vs default', flush=True)
+    print(f'# ViTPose-{variant.upper()} / {dataset}, {n} crops (M = {192 * n}, D = {shp.embed_dim}): ms per step (hipGraph replay, {args.iters} calls) | us per layer: qkv fc1 proj fc2 attention | kernels | keypoints vs default', flush=True)
     ref = None
     for name, tune in sets:
+        tune, _, sk = tune.partition('|')
+        if sk:
+            os.environ['VP_SPLITK'] = sk
+        else:
+            os.environ.pop('VP_SPLITK', None)
         if tune:
             os.environ['VP_GEMM_TUNE'] = tune
         else:
@@ -70,7 +77,7 @@ for case in args.cases.split(','):
             for _ in range(10):
                 eng.infer_device(crops, out, sync=True, ordered=False)
             p = eng.profile()
-            us = {f: 1e3 * p[f]['ms'] / max(1, p[f]['launches']) for f in ('gemm_qkv', 'gemm_fc1', 'gemm_proj', 'gemm_fc2', 'attention')}
+            us = {f: 1e3 * p[f]['ms'] / (10 * shp.depth) for f in ('gemm_qkv', 'gemm_fc1', 'gemm_proj', 'gemm_fc2', 'attention')}
             kern = ' | '.join(eng.profile_kernel(f).split('TileCfg')[-1] for f in ('gemm_qkv', 'gemm_fc1', 'gemm_proj', 'gemm_fc2'))
             eng.close()
         except Exception as e:   # a configuration that does not launch for this shape
@@ -78,5 +85,5 @@ for case in args.cases.split(','):
             continue
         if ref is None:
             ref = kp
-        same = 'identical' if np.array_equal(kp, ref) else f'DIFFERENT (max {np.abs(kp - ref).max():.3g})'
+        same = 'identical' if np.array_equal(kp, ref) else f'differs from the first set (max {np.abs(kp - ref).max():.3g})'
         print(f'{name:10s} {ms:7.3f} ms | ' + ' '.join(f'{us[f]:6.1f}' for f in us) + f' | {kern} | {same}', flush=True)
