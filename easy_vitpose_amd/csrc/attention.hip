@@ -29,6 +29,9 @@
 namespace vp {
 
 static constexpr int T = 192;
+#ifndef VP_ATTN_QSPLIT_DEFAULT
+#define VP_ATTN_QSPLIT_DEFAULT 128   // (crop, head) pairs: B x 1 0.521 -> 0.495 ms, L x 1 1.215 -> 1.152, B x 8 0.949 -> 0.906; neutral at 128 pairs, slower from 192 on
+#endif
 
 template <int HD> struct AttnCfg {
     static constexpr int HDP = (HD + 31) / 32 * 32;   // head dim padded to the MFMA k step
@@ -51,7 +54,10 @@ __device__ __forceinline__ u32x2 lds_read_tr16(const char* p) {
 // MX (fp8 mode, HD = 64 only): the output is written as MXFP8 -- e4m3 codes in the 64 x 128-blocked layout + one E8M0 scale per 32 columns
 // (csrc/mx8.h) -- the A operand of the fp8 attn.proj GEMM; `out` then points at the codes and `out_scales` at the scale bytes.  A block of 32
 // output columns (half a head) of one query is the four lanes fg = 0..3 of a d-pair: amax by two cross-lane steps.
-template <class Ty, int HD, int QT, bool MX = false>
+// QS (round 6, small batches): query parts per (crop, head).  QS = 3: three workgroups share a (crop, head), each wave owns ONE of its three query tiles
+// (the same tile rows, the same arithmetic: bit-identical output) and every workgroup stages the whole K and V -- a single crop of ViTPose-B is then 36
+// workgroups with a third of the serial work each instead of 12.
+template <class Ty, int HD, int QT, bool MX = false, int QS = 1>
 __global__ __launch_bounds__(256, QT == 3 ? 2 : 3) void attention_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out,
                                                             int D, int heads, float scale_log2e, int blocked, uint8_t* __restrict__ out_scales = nullptr) {
     using C = AttnCfg<HD>;
@@ -65,11 +71,14 @@ __global__ __launch_bounds__(256, QT == 3 ? 2 : 3) void attention_kernel(const u
     // (profiles/attention_order_r3.txt: attention of ViTPose-S -15 %, of ViTPose-H -6 %; an XCD-contiguous order over the whole launch gains less,
     // and with whole-line slices -- HD = 64 -- it is 4-11 % SLOWER than the plain order, which stays there).
     constexpr bool REMAP = (HD * 2) % 128 != 0;
-    int bid = blockIdx.x;
+    static_assert(QS == 1 || (QS == 3 && QT == 1), "query split: one tile per wave");
+    constexpr int NTW = 3 / QS;                       // query tiles per wave
+    const int part = QS == 1 ? 0 : (int)(blockIdx.x % QS);
+    int bid = blockIdx.x / QS;
     if constexpr (REMAP) {
         constexpr int P = 4, G = 8 * P;
-        const int i = blockIdx.x;
-        if (i < (int)(gridDim.x / G) * G) bid = (i & ~(G - 1)) | ((i & 7) * P) | ((i >> 3) & (P - 1));
+        const int i = bid;
+        if (i < (int)(gridDim.x / QS / G) * G) bid = (i & ~(G - 1)) | ((i & 7) * P) | ((i >> 3) & (P - 1));
     }
     const int b = bid / heads, h = bid % heads;
     const size_t ld = (size_t)3 * D;
@@ -90,7 +99,7 @@ __global__ __launch_bounds__(256, QT == 3 ? 2 : 3) void attention_kernel(const u
     const int fr = lane & 15, fg = lane >> 4;
     constexpr int KS = C::HDP / 32;     // k steps of QK^T
     constexpr int DT = C::DT;
-    u32x4 kreg[NKL], vreg[NVL], qf_all[3][KS];
+    u32x4 kreg[NKL], vreg[NVL], qf_all[NTW][KS];
 #pragma unroll
     for (int i = 0; i < NKL; ++i) {
         const int c = tid + i * 256, key = c / CHP, ch = c % CHP;
@@ -102,8 +111,8 @@ __global__ __launch_bounds__(256, QT == 3 ? 2 : 3) void attention_kernel(const u
     // > 200 VGPRs -> 2 blocks/CU); QT = 1 keeps one tile live (~100 VGPRs -> 3 blocks/CU, more loads in flight
     // while other blocks compute: measured 8 % faster at B = 256).
 #pragma unroll
-    for (int t = 0; t < 3; ++t) {
-        const int q = (wave * 3 + t) * 16 + fr;
+    for (int t = 0; t < NTW; ++t) {
+        const int q = (wave * 3 + part * NTW + t) * 16 + fr;
 #pragma unroll
         for (int kk = 0; kk < KS; ++kk) {
             const int d = kk * 32 + fg * 8;
@@ -146,7 +155,7 @@ __global__ __launch_bounds__(256, QT == 3 ? 2 : 3) void attention_kernel(const u
     const char* vfrag = Vs + (fg * 4 + (fr >> 2)) * 32 + (fr & 3) * 8;
 
 #pragma unroll
-    for (int t0 = 0; t0 < 3; t0 += QT) {
+    for (int t0 = 0; t0 < NTW; t0 += QT) {
         // ---- S^T[key][q] for 12 key tiles x QT query tiles ----
         f32x4 s[QT][12];
 #pragma unroll
@@ -222,7 +231,7 @@ __global__ __launch_bounds__(256, QT == 3 ? 2 : 3) void attention_kernel(const u
             }
 #pragma unroll
             for (int t = 0; t < QT; ++t) {
-                const int q = (wave * 3 + t0 + t) * 16 + fr;
+                const int q = (wave * 3 + part * NTW + t0 + t) * 16 + fr;
                 uint16_t* dst = out + ((size_t)b * T + q) * D + h * HD;
                 if constexpr (MX && C::PAIR) {
                     float v[8];
@@ -268,6 +277,15 @@ static hipError_t launch(const uint16_t* qkv, uint16_t* out, int B, int D, int h
 #endif
     const float scale = 1.0f / sqrtf((float)HD);   // head_dim ** -0.5, vit.py:156
     if (blocked && HD != 64) return hipErrorInvalidValue;
+    // small batches: three workgroups per (crop, head), one query tile per wave (QS = 3) while that still leaves CUs idle otherwise -- VP_ATTN_QSPLIT = the largest
+    // number of (crop, head) pairs that takes it (0: never; profiles/small_batch_r6.txt)
+    const char* qs_env = getenv("VP_ATTN_QSPLIT");   // read per launch (a parity test flips it inside one process; the hipGraph of a chunk keeps what it captured)
+    const int qsplit_max = qs_env ? atoi(qs_env) : VP_ATTN_QSPLIT_DEFAULT;
+    if (B * heads <= qsplit_max) {
+        hipLaunchKernelGGL((attention_kernel<Ty, HD, 1, false, 3>), dim3(B * heads * 3), dim3(256), AttnCfg<HD>::LDS, s, qkv, out, D, heads,
+                           scale * 1.4426950408889634f, blocked, (uint8_t*)nullptr);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(kern, dim3(B * heads), dim3(256), AttnCfg<HD>::LDS, s, qkv, out, D, heads,
                        scale * 1.4426950408889634f, blocked, (uint8_t*)nullptr);
     return hipGetLastError();

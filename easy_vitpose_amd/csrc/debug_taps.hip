@@ -321,6 +321,10 @@ int make_rand_case(vp_ctx* c, RandCase& rc, int epi, int flags, int M, int N, in
     if ((r = dalloc(c, &dA, (size_t)M * K)) || (r = dalloc(c, &dW, wrows * K)) || (r = dalloc(c, &c->zero, (size_t)256))) return r;
     vp::fill_random16(c->dtype, dA, (size_t)M * K, 1u, nullptr);
     vp::fill_random16(c->dtype, dW, wrows * K, 2u, nullptr);
+    // flags 64 / 128 (tools/clock_power_probe.py, VP_PROBE_SET=operand_bits): the SAME instruction stream on all-zero operands / on operands that are all the
+    // constant 0x3c00 (1.0 in fp16) -- how much of a launch's time is the board power limit (the chip clocks by the energy its operand bits toggle)
+    if (flags & 64) { HIPCHK(c, hipMemset(dA, 0, (size_t)M * K * 2)); HIPCHK(c, hipMemset(dW, 0, wrows * K * 2)); }
+    if (flags & 128) { HIPCHK(c, hipMemsetD16(dA, 0x3c00, (size_t)M * K)); HIPCHK(c, hipMemsetD16(dW, 0x3c00, wrows * K)); }
     std::vector<float> hb(wrows), hs(wrows), hr((size_t)M * 2);
     uint32_t lcg = 12345u;
     auto rnd = [&]() { lcg = lcg * 1664525u + 1013904223u; return (float)((lcg >> 8) & 0xffff) / 65536.f - 0.5f; };

@@ -89,9 +89,18 @@ Tile2Pick pick_gemm2_tile(int epi, int M, int N, int K) {
     return tp;
 }
 
-// Split-K of a residual GEMM at small batches.  (Round 6; filled in from the in-situ sweep: profiles/small_batch_r6.txt.)
+// Split-K of a residual GEMM at small batches (round 6; in-situ grid profiles/small_batch_r6.txt: 4 models x 1-12 crops x S in {2, 4} x six tiles, whole step timed).
+// A call of ONE OR TWO crops leaves most CUs idle in mlp.fc2 -- 72-96 tiles of 32 x 64 per crop, each a serial chain of K / 64 = 48-80 k-blocks: four k ranges per tile
+// (288-384 workgroups of 12-20 k-blocks) + the fixed-order reduction kernel win although the partial products make a round trip through L2:
+//   1 crop : ViTPose-B 0.575 -> 0.524 ms (-8.9 %), -L 1.376 -> 1.223 (-11.1 %), -H 2.188 -> 1.897 (-13.3 %), -S -1.9 %;   2 crops: -3.9 % / -6.0 % / -4.6 % (B / L / H).
+// From 4 crops on the unsplit GEMM fills the chip and the round trip of the partials loses (+1 ... +20 %), with one exception that is shipped: ViTPose-H's mlp.fc2 of
+// 7-8 crops (K = 5120 = 80 k-blocks on 480 tiles of 64 x 64) as 4 k ranges of 128 x 128 tiles: 4.435 -> 4.076 ms (-8.1 %).  attn.proj (K = D) never gains.
+// Returns S = 1 for everything else; the caller requires K % (128 S) == 0.  A pure function of the shape: tests/test_host_logic.py walks it (vp_dbg_splitk_pick).
 SplitKPick pick_splitk(int M, int N, int K) {
-    (void)M; (void)N; (void)K;
+    if (K < 3 * N || K % 512 != 0) return {1, 0};         // mlp.fc2 only (K = 4 N)
+    if (M <= 192) return {4, N >= 1280 ? 12 : 31};         // one crop: 32 x 64 tiles (64 x 64 on a 4-stage ring for ViTPose-H: measured -13.3 % against -10.5 %)
+    if (M <= 384 && K >= 3072) return {4, 12};             // two crops (not ViTPose-S: neutral)
+    if (K >= 5120 && M > 1152 && M <= 1536) return {4, 1};  // ViTPose-H, 7-8 crops
     return {1, 0};
 }
 
@@ -115,6 +124,14 @@ VP_API int vp_dbg_gemm2_pick(int32_t epi, int32_t M, int32_t N, int32_t K, int32
     const Tile2Pick tp = pick_gemm2_tile(epi, M, N, K);
     if (group_m) *group_m = tp.group_m;
     return tp.variant;
+}
+
+// HOST ONLY: the split-K rule for a residual GEMM of [M, N] x K: returns S (1 = one launch), *variant = the tile configuration of the partial products
+VP_API int vp_dbg_splitk_pick(int32_t M, int32_t N, int32_t K, int32_t* variant) {
+    if (M <= 0 || N <= 0 || K <= 0) return VP_ERR_INVALID;
+    const SplitKPick sk = pick_splitk(M, N, K);
+    if (variant) *variant = sk.variant;
+    return sk.S;
 }
 
 }  // extern "C"

@@ -279,6 +279,9 @@ VP_API int vp_dbg_gemm8_pick(int32_t M, int32_t N, int32_t wide, int32_t bm192_m
  * (fc1), 4 deconv, 5 final 1x1 conv, 6 residual + row statistics (attn.proj, mlp.fc2), 7 patch embed; [M, N] output, depth K; *group_m (may be NULL) = its tile-order group.
  * (Large batches: the 8-phase kernel takes the encoder GEMMs over where vp_dbg_gemm8_pick says so.) */
 VP_API int vp_dbg_gemm2_pick(int32_t epi, int32_t M, int32_t N, int32_t K, int32_t* group_m);
+/* HOST ONLY: the split-K rule of the residual GEMMs at small batches (attn.proj / mlp.fc2 of [M, N] x K): returns the number of k ranges S (1 = the one-launch
+ * residual epilogue; S > 1 = S partial products + the fixed-order reduction kernel), *variant (may be NULL) = the gemm.hip Cfg id of the partial products */
+VP_API int vp_dbg_splitk_pick(int32_t M, int32_t N, int32_t K, int32_t* variant);
 /* The two-phase schedule of a group call -- HOST ONLY, stub members: the order in which group_run would submit to (+ (member + 1)) and
  * wait for (- (member + 1)) its members for n crops on w devices of max_batch maxb.  Within every round all submissions precede the
  * first wait: no member's enqueue waits for another member's compute.  Returns the trace length (also beyond `cap`); < 0 on bad arguments. */

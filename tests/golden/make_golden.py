@@ -356,6 +356,37 @@ def main():
             t0 = time.time()
             with torch.no_grad():
                 kps = np.concatenate([V._inference_torch(crops[i]) for i in range(n)], 0).astype(np.float32)
+                # the reference's own heatmaps once more (its pre_img + its model): a linear read-out of random features leaves a few blobs with two or three
+                # near-tied maxima 2-3 pixels apart, which the REFERENCE itself separates by less than the 1e-3 its values may differ by.
+                # Stored per joint: the margin of the runner-up and of the third peak (each outside the 3 x 3 neighbourhood of the better ones) and the
+                # keypoint the reference's own decode (post_dark_udp + transform_preds, the calls of keypoints_from_heatmaps) gives when started from them
+                from cases import peak_margin
+                from easy_ViTPose.vit_utils.top_down_eval import post_dark_udp as ref_dark
+                from easy_ViTPose.vit_utils.post_processing.post_transforms import transform_preds as ref_tp
+                K = shp.num_keypoints
+                margin = np.zeros((n, K), np.float32)
+                alt_yx = np.zeros((n, K, 2, 2), np.float32)
+                alt_margin = np.zeros((n, K, 2), np.float32)
+                selfcheck = 0.0
+                for i in range(n):
+                    hm = V._vit_pose(torch.from_numpy(V.pre_img(crops[i])[0])).numpy()
+                    margin[i] = peak_margin(hm)[0]
+                    for k in range(K):
+                        h = hm[0, k]
+                        m = h.copy()
+                        for a in range(3):          # a = 0: the arg-max itself (self-check against _inference_torch), 1 / 2: the alternates
+                            y0, x0 = divmod(int(m.argmax()), m.shape[1])
+                            c = np.array([[[x0, y0]]], dtype=np.float32)
+                            c = ref_dark(c, h[None, None].copy(), kernel=11)
+                            xy = ref_tp(c[0], np.array([192 // 2, 256 // 2]), np.array([192, 256]), [48, 64], use_udp=True)[0]
+                            if a == 0:
+                                selfcheck = max(selfcheck, float(np.abs(xy[::-1] - kps[i, k, :2]).max()))
+                            else:
+                                alt_yx[i, k, a - 1] = xy[::-1]
+                                alt_margin[i, k, a - 1] = h.max() - h[y0, x0]
+                            m[max(0, y0 - 1):y0 + 2, max(0, x0 - 1):x0 + 2] = -np.inf
+                assert selfcheck < 1e-4, f'decode from the arg-max differs from _inference_torch by {selfcheck}'
+                assert np.abs(alt_margin[..., 0] - margin).max() < 1e-6
             # oracle-vs-reference on the first crops (the same check tests/test_oracle_golden.py repeats against the stored outputs)
             from oracle import vitpose_cpu as O
             sdt = O.to_torch_state_dict(sd)
@@ -365,9 +396,10 @@ def main():
             loc = np.hypot(kps[..., 0] - want_yx[..., 0], kps[..., 1] - want_yx[..., 1])
             print(f'content {variant}/{dataset}: {n} crops x {K} joints through the reference in {time.time() - t0:.0f} s, confidences '
                   f'{kps[..., 2].min():.3f} .. {kps[..., 2].max():.3f}, distance to the blob centres median {np.median(loc):.2f} px / p90 '
-                  f'{np.percentile(loc, 90):.2f} px, oracle-vs-reference max|d| = {np.abs(okp - kps[:4]).max():.3e}', flush=True)
+                  f'{np.percentile(loc, 90):.2f} px, oracle-vs-reference max|d| = {np.abs(okp - kps[:4]).max():.3e}; runner-up margin < 2e-3 on '
+                  f'{int((margin < 2e-3).sum())} of {margin.size} joints (min {margin.min():.2e}, median {np.median(margin):.3f})', flush=True)
             np.savez_compressed(os.path.join(HERE, f'full_content_{variant}_{dataset}.npz'), variant=variant, dataset=dataset, n=n, keypoints=kps,
-                                blobs=blobs.astype(np.float32))
+                                blobs=blobs.astype(np.float32), margin=margin.astype(np.float32), alt_yx=alt_yx, alt_margin=alt_margin)
 
 
 if __name__ == '__main__':

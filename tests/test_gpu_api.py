@@ -500,3 +500,40 @@ def test_video_mode_with_tracker_and_cli(tmp_path):
     out = json.load(open(tmp_path / 'out' / 'clip.npy' / 'clip_result.json'))
     assert len(out['keypoints']) == 6 and out['skeleton']['0'] == 'nose'
     assert sorted(out['keypoints'][0].keys()) == ['1', '2'] and len(out['keypoints'][0]['1']) == 17 and len(out['keypoints'][0]['1'][0]) == 3
+
+@pytest.mark.parametrize('variant,dataset', [('b', 'coco'), ('h', 'wholebody'), ('s', 'coco')])
+def test_split_k_single_crop_calls_meet_the_tolerances_and_are_deterministic(golden_dir, variant, dataset, monkeypatch):
+    """Round 6: calls of one or two crops (the reference's own per-person call, inference.py:259-272) run mlp.fc2 as four k ranges + the fixed-order reduction
+    kernel (tile_rules.hip pick_splitk).  The accumulation order differs from the batched kernels, so these calls are no longer bit-identical to larger batches --
+    what is asserted is what the north_star asks: every joint of the peaked golden within +-0.5 px / 1e-3 of the REFERENCE's keypoints, crop by crop and two at a
+    time; run-to-run bit identity (no atomics anywhere); and the same against the one-launch path (VP_SPLITK=0), which must stay inside the same tolerances."""
+    from cases import peaked_crops
+    from easy_vitpose_amd.configs import model_shape
+    from easy_vitpose_amd.synth import synthetic_state_dict
+    z = np.load(os.path.join(golden_dir, f'peaked_{variant}_{dataset}.npz'))
+    n = int(z['n'])
+    shp = model_shape(variant, dataset)
+    sd = synthetic_state_dict(shp, 0, peaked=True)
+    crops, ref = peaked_crops(n), z['keypoints']
+    got = {}
+    for tag, env in (('split-K', None), ('one launch', '0')):
+        if env is None:
+            monkeypatch.delenv('VP_SPLITK', raising=False)
+        else:
+            monkeypatch.setenv('VP_SPLITK', env)
+        eng = VitPoseHip(shp, sd, dtype='fp16', device_id=0, max_batch=2)
+        one = np.concatenate([eng.infer(crops[i:i + 1]) for i in range(n)])
+        one_again = np.concatenate([eng.infer(crops[i:i + 1]) for i in range(n)])
+        kern = eng.profile_kernel('gemm_fc2')          # of the single-crop calls (ViTPose-S does not split two-crop calls)
+        two = np.concatenate([eng.infer(crops[i:i + 2]) for i in range(0, n, 2)])
+        eng.close()
+        assert np.array_equal(one, one_again), f'{tag}: single-crop calls are not run-to-run deterministic'
+        assert ('split-K' in kern) == (env is None), f'{tag}: mlp.fc2 ran on {kern}'
+        for what, kp in (('1 crop per call', one), ('2 crops per call', two)):
+            dpx = np.abs(kp[..., :2] - ref[..., :2]).max(-1)
+            dcf = np.abs(kp[..., 2] - ref[..., 2])
+            print(f'[{variant}/{dataset} {tag}, {what}] {dpx.size} joints: coordinate max err {dpx.max():.4f} px, confidence max err {dcf.max():.3e}; fc2 = {kern}')
+            assert dpx.max() < 0.5 and dcf.max() < 1e-3, (tag, what)
+        got[tag] = one
+    d = np.abs(got['split-K'] - got['one launch'])      # (not a parity statement: a different fp32 accumulation order in mlp.fc2, through L blocks and the head)
+    print(f'[{variant}/{dataset}] split-K against the one-launch path: coordinates differ by up to {d[..., :2].max():.4f} px, confidences by up to {d[..., 2].max():.3e}')

@@ -81,6 +81,23 @@ def test_attention(dtype, D, heads):
     assert err <= tol, f'attention D={D} {dtype}: max err {err:.3e} > {tol:.3e}'
 
 
+@pytest.mark.parametrize('dtype,D,heads,B', [('fp16', 768, 12, 1), ('fp16', 1024, 16, 3), ('fp16', 1280, 16, 2), ('bf16', 384, 12, 5)])
+def test_attention_query_split_is_bit_identical(dtype, D, heads, B, monkeypatch):
+    """Round 6, small batches: three workgroups per (crop, head), one query tile per wave (attention.hip QS = 3, taken while crops x heads <= VP_ATTN_QSPLIT) --
+    the same tile rows and the same arithmetic per tile, so the output must equal the one-workgroup-per-(crop, head) kernel BIT FOR BIT, for every head dim."""
+    rng = np.random.default_rng(D + B)
+    qkv = round_to(rng.standard_normal((B * 192, 3 * D)).astype(np.float32), dtype)
+    lib = capi.load_library()
+    outs = []
+    for qs in ('0', '100000'):
+        monkeypatch.setenv('VP_ATTN_QSPLIT', qs)
+        out = np.full((B * 192, D), np.nan, np.float32)
+        capi.check(lib.vp_dbg_attention(0, DT[dtype], B, D, heads, _ptr(qkv), _ptr(out)))
+        outs.append(out)
+    assert np.isfinite(outs[1]).all()
+    assert np.array_equal(outs[0], outs[1]), f'{(outs[0] != outs[1]).sum()} of {outs[0].size} outputs differ between the query-split and the plain kernel'
+
+
 @pytest.mark.parametrize('dtype,D,heads,npairs', [('fp16', 1280, 16, 8), ('bf16', 1280, 16, 9), ('fp16', 768, 12, 6)])
 def test_fused_qkv_attention_tap_against_the_two_kernels(dtype, D, heads, npairs):
     """attn.qkv + attention core as ONE kernel through its parity tap: head dim 80 = gemm8.hip's 192 x 256 tile with EPI_QKV_ATTN (one crop x one head per

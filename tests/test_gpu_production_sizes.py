@@ -243,26 +243,37 @@ def test_content_dependent_checkpoint_against_the_reference_itself(golden_dir, v
     """the first end-to-end test in which an ENCODER error moves a coordinate.  Checkpoint = cases.content_state_dict (every tensor
     of the backbone and of both deconvs seeded-random; `final_layer` ridge-fitted on the 256 head features, stored as a fixture) -- joint k's heatmap
     peaks on colour blob k % 3 of the crop, so the keypoint locations are a function of the crop through all L blocks (tests/test_oracle_golden.py::
-    test_content_goldens_are_a_function_of_the_crop).  64 crops x every BASELINE model against the keypoints the REFERENCE produced crop by crop
-    (full_content_*.npz, make_golden.py --only=content): +-0.5 px and 1e-3 on EVERY joint, the north_star's tolerances."""
-    from cases import content_crops, content_state_dict
+    test_content_goldens_are_a_function_of_the_crop; tests/precision_budget.py --content: the encoder owns 46 % of the confidence AND of the coordinate
+    error variance here, against 0.2-3 % on the `peaked` checkpoints).  64 crops x every BASELINE model against the keypoints the REFERENCE produced crop
+    by crop (full_content_*.npz, make_golden.py --only=content), EVERY joint at the north_star's tolerances:
+      * confidence within 1e-3 of the reference's;
+      * coordinates within +-0.5 px of the reference's keypoint -- or, where the reference's own heatmap has a second (third) peak within cases.CONTENT_TIE =
+        3e-3 of its maximum, of the keypoint the reference's decode gives from that peak (a linear read-out of random features leaves 5-8 % of the blobs
+        with two maxima 2-3 pixels apart that the reference separates by less than the values may differ: a 1e-4 RELATIVE perturbation of the reference's
+        fp32 heatmaps moves some of them by 0.3 px).  The alternates are part of the golden (the reference's post_dark_udp + transform_preds started
+        from the runner-up); how many joints needed one is printed and bounded."""
+    from cases import content_coordinate_error, content_crops, content_state_dict
     z = np.load(os.path.join(golden_dir, f'full_content_{variant}_{dataset}.npz'))
     assert int(z['n']) == n
     shp, sd = content_state_dict(variant, dataset)
     crops, _ = content_crops(n)
     eng = VitPoseHip(shp, sd, dtype='fp16', device_id=0, max_batch=n)
     kp = eng.infer(crops)
-    kp8 = np.concatenate([eng.infer(crops[i:i + 8]) for i in (0, 8)])          # the small-batch kernels (split-K, one workgroup per tile) on the same crops
+    kp8 = np.concatenate([eng.infer(crops[i:i + 8]) for i in (0, 8)])          # the small-batch kernels (one workgroup per tile) on the same crops
+    kp1 = np.concatenate([eng.infer(crops[i:i + 1]) for i in (0, 1, 2, 3)])     # ... and the single-crop call of the reference (inference.py:268): split-K mlp.fc2
     eng.close()
     ref = z['keypoints']
     assert kp.shape == ref.shape == (n, shp.num_keypoints, 3) and np.isfinite(kp).all()
-    for tag, got, want in (('one call', kp, ref), ('8-crop calls', kp8, ref[:16])):
-        dpx = np.abs(got[..., :2] - want[..., :2]).max(-1)
+    for tag, got in (('one call', kp), ('8-crop calls', kp8), ('1-crop calls', kp1)):
+        want = ref[:len(got)]
+        dpx, which = content_coordinate_error(got[..., :2], z)
         dcf = np.abs(got[..., 2] - want[..., 2])
-        print(f'[content {variant}/{dataset} x {len(got)}, {tag}, vs the reference] {dpx.size} joints: coordinate max err {dpx.max():.4f} px (mean {dpx.mean():.5f}), '
-              f'confidence max err {dcf.max():.3e} (rms {np.sqrt((dcf ** 2).mean()):.3e}), confidences {want[..., 2].min():.3f} .. {want[..., 2].max():.3f}')
+        print(f'[content {variant}/{dataset} x {len(got)}, {tag}, vs the reference] {dpx.size} joints: coordinate max err {dpx.max():.4f} px (mean {dpx.mean():.5f}; '
+              f'{(which > 0).sum()} joints on a near-tied alternate peak of the reference), confidence max err {dcf.max():.3e} (rms {np.sqrt((dcf ** 2).mean()):.3e}), '
+              f'confidences {want[..., 2].min():.3f} .. {want[..., 2].max():.3f}')
         assert dpx.max() < KP_TOL_PX, tag
         assert dcf.max() < CONF_TOL, tag
+        assert (which > 0).mean() <= 0.02, f'{tag}: {(which > 0).sum()} joints needed an alternate peak'
 
 
 def test_noise_map_confidence_statistic_vitpose_h():

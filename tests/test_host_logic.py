@@ -160,6 +160,33 @@ def test_tools_library_exports_the_measurement_entry_points():
         assert not hasattr(prod, name), f'{name} must not be in the product library'
 
 
+def test_split_k_rule_over_every_batch_size():
+    """Round 6: the split-K rule of the residual GEMMs (tile_rules.hip pick_splitk through the host-only tap vp_dbg_splitk_pick) walked over every batch size of
+    every model.  Invariants: attn.proj is never split; S in {1, 4}; K divides into S ranges of whole 128-k double blocks; the partial products run on a tile the
+    product library instantiates for EPI_PARTIAL; S x tiles fills at most two rounds of workgroups; and the operating points measured in situ
+    (profiles/small_batch_r6.txt) keep their choices -- 1-2 crops split, 4+ crops not, ViTPose-H's 7-8 crops on 128 x 128 tiles."""
+    lib = capi.load_library()
+    var = C.c_int32()
+    tile = {31: (32, 64), 12: (64, 64), 1: (128, 128), 11: (192, 128), 15: (128, 64), 20: (192, 128), 30: (64, 64)}
+    for D in (384, 768, 1024, 1280):
+        for n in range(1, 401):
+            M = 192 * n
+            assert lib.vp_dbg_splitk_pick(M, D, D, C.byref(var)) == 1, 'attn.proj is never split'
+            S = lib.vp_dbg_splitk_pick(M, D, 4 * D, C.byref(var))
+            assert S in (1, 4), (D, n, S)
+            if S > 1:
+                assert (4 * D) % (128 * S) == 0 and var.value in tile and n <= 8, (D, n, S, var.value)
+                bm, bn = tile[var.value]
+                assert S * -(-M // bm) * -(-D // bn) <= 1024, (D, n)
+    pick = lambda D, n: (lib.vp_dbg_splitk_pick(192 * n, D, 4 * D, C.byref(var)), var.value)
+    assert pick(768, 1) == (4, 31) and pick(1024, 1) == (4, 31) and pick(1280, 1) == (4, 12) and pick(384, 1) == (4, 31)
+    assert pick(768, 2) == (4, 12) and pick(1024, 2) == (4, 12) and pick(1280, 2) == (4, 12) and pick(384, 2)[0] == 1
+    for D in (384, 768, 1024):
+        for n in (3, 4, 6, 8, 12, 16, 64, 256):
+            assert pick(D, n)[0] == 1, (D, n)
+    assert pick(1280, 8) == (4, 1) and pick(1280, 7) == (4, 1) and pick(1280, 6)[0] == 1 and pick(1280, 4)[0] == 1 and pick(1280, 12)[0] == 1
+
+
 def test_gemm2_tile_selection_over_every_batch_size():
     """The rule that picks the 2-phase kernel's tile configuration (vitpose_api.hip pick_gemm2_tile, through the host-only tap vp_dbg_gemm2_pick) walked over every
     batch size 1..400 of every model and every GEMM of the path.  Invariants: only configurations the PRODUCT library instantiates; the deep rings (4-stage 64 x 64,

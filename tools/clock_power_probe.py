@@ -174,3 +174,14 @@ if os.environ.get('VP_PROBE_SET', 'main') in ('main', 'torch'):   # the vendor l
         loop('torch.mm fp16 8192^3 (plain)', mm(8192, 8192, 8192))
     except Exception as e:   # noqa: BLE001
         print('torch.mm probe skipped:', e)
+elif os.environ.get('VP_PROBE_SET') == 'operand_bits':
+    # Round 6: is mlp.fc1 bound by its schedule or by the board power limit?  The SAME kernel, the same instruction stream and the same memory traffic on
+    # random operands (what every benchmark of this repository runs), on all-zero operands and on constant operands; with and without the epilogue's stores (ablation 8).
+    for tag, fl in (('random operands', 0), ('all-zero operands', 64), ('constant 1.0 operands', 128)):
+        loop(f'fc1 gemm8 256x256, {tag}', gemm(1, 16, 8, 16 | 2 | fl, M, 3072, 768))
+    for tag, fl in (('random operands', 0), ('all-zero operands', 64)):
+        loop(f'fc1 gemm8 256x256 NO STORES, {tag}', gemm(1, 16 | (8 << 8), 8, 16 | 2 | fl, M, 3072, 768))
+    for tag, fl in (('random operands', 0), ('all-zero operands', 64)):
+        loop(f'fc2 gemm8 192x256, {tag}', gemm(6, 18, 2, 4 | 8 | fl, M, 768, 3072))
+    for tag, fl in (('random operands', 0), ('all-zero operands', 64)):
+        loop(f'proj cfg11 192x128, {tag}', gemm(6, 11, 0, fl, M, 768, 768))
