@@ -517,7 +517,7 @@ __global__ __launch_bounds__(C::NT, 2) void gemm_kernel(GemmArgs g) {
         // deconv2 + folded BN + ReLU with the final 1x1 conv fused behind it (topdown_heatmap_simple_head.py:188-193): the tile
         // holds ALL 256 channels of its 256 output pixels, so the 16-bit activations go to LDS instead of HBM (the [B,64,48,256]
         // tensor, 402 MB at batch 256, is never written or read) and a second small MFMA product with the hi + lo final-layer
-        // weights (vitpose_api.hip upload_final: [16 hi rows][16 lo rows] groups) gives the heatmaps.  Arithmetic and
+        // weights (weights.hip upload_final: [16 hi rows][16 lo rows] groups) gives the heatmaps.  Arithmetic and
         // accumulation order are those of EPI_DECONV followed by EPI_HEATMAP (k ascending in steps of 32, hi and lo products
         // in separate accumulators, hi + lo, + bias): bit-identical heatmaps -- tests/test_gpu_gemm_cfgs.py, test_gpu_api.py.
         static_assert(C::BN == 256 && C::BM % (C::NWAVES * 16) == 0, "the fused head needs all 256 channels in one tile");
@@ -884,7 +884,7 @@ __global__ __launch_bounds__(C::NT, 2) void gemm_kernel(GemmArgs g) {
                 orow = (size_t)m * g.ldo;
             }
             if constexpr (EPI == EPI_HEATMAP) {
-                // weight rows come as [16 hi][16 lo] groups (vitpose_api.hip upload_final): fragments 2u and 2u + 1
+                // weight rows come as [16 hi][16 lo] groups (weights.hip upload_final): fragments 2u and 2u + 1
                 // are the hi and lo products of output columns (n0 + wn WN) / 2 + 16 u + 4 fg .. + 3
 #pragma unroll
                 for (int u = 0; u < C::TI / 2; ++u) {
@@ -1237,6 +1237,11 @@ using Cfg29 = TileCfg<64, 64, 64, 32, 32, 4, 6, 0>;     //  64 KiB   4   (2 bloc
 using Cfg30 = TileCfg<64, 64, 64, 32, 32, 6, 6, 0>;     //  96 KiB   4   (1 block / CU)   ... 6-stage ring (4 in flight)
 using Cfg31 = TileCfg<32, 64, 64, 16, 32, 6, 6, 0>;     //  72 KiB   4   (2 blocks / CU)  32(m) x 64(n): twice the workgroups of a 1-2 crop GEMM, half the MFMAs per wave and k-block
 using Cfg32 = TileCfg<32, 64, 64, 16, 32, 8, 6, 0>;     //  96 KiB   4   (1 block / CU)   ... 8-stage ring (6 in flight)
+// round 6: the staggered two-group schedule (PIPE 3: waves 0-3 / 4-7 one barrier apart -- one group's fragment reads and DMA run beside the other group's MFMAs) on tiles a
+// few crops fill: the one-barrier-per-k-block loop spends 80 % of a Cfg20 launch in its own schedule (LDS reads and MFMAs never overlap across waves; profiles/small_batch_r6.txt call 6)
+using Cfg33 = TileCfg<256, 128, 32, 64, 64, 4, 3, 0>;   //  96 KiB   8   (1 block / CU)   256(m) x 128(n), k-blocks of 32, 4-stage ring
+using Cfg34 = TileCfg<128, 128, 32, 32, 64, 4, 3, 0>;   //  64 KiB   8   (2 blocks / CU)  128 x 128
+using Cfg35 = TileCfg<128, 256, 32, 32, 128, 4, 3, 0>;  //  96 KiB   8   (1 block / CU)   128(m) x 256(n)
 
 template <class T, int EPI, int AMODE, class C>
 static hipError_t launch(const GemmArgs& a, hipStream_t s) {
@@ -1274,7 +1279,7 @@ static hipError_t launch(const GemmArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
-// the product library carries the configurations the selection rule of vitpose_api.hip gemm() can pick (1, 3, 8, 9, 11, 12, 15, 30, 31);
+// the product library carries the configurations the selection rule of tile_rules.hip can pick (1, 3, 8, 9, 11, 12, 15, 20, 30, 31);
 // the measured alternatives are instantiated in the VP_TOOLS build only
 #ifdef VP_TOOLS
 #define VP_TOOLS_CASE(v) case v: return launch<T, EPI, AMODE, Cfg##v>(a, s);
@@ -1301,7 +1306,7 @@ static hipError_t by_variant(const GemmArgs& a, hipStream_t s) {
         VP_TOOLS_CASE(14)
         case 15: return launch<T, EPI, AMODE, Cfg15>(a, s);
         VP_TOOLS_CASE(19)
-        VP_TOOLS_CASE(20)
+        case 20: return launch<T, EPI, AMODE, Cfg20>(a, s);
         VP_TOOLS_CASE(21)
         VP_TOOLS_CASE(22)
         VP_TOOLS_CASE(23)
@@ -1314,6 +1319,9 @@ static hipError_t by_variant(const GemmArgs& a, hipStream_t s) {
         case 30: return launch<T, EPI, AMODE, Cfg30>(a, s);
         case 31: return launch<T, EPI, AMODE, Cfg31>(a, s);
         VP_TOOLS_CASE(32)
+        VP_TOOLS_CASE(33)
+        VP_TOOLS_CASE(34)
+        VP_TOOLS_CASE(35)
     }
     return hipErrorInvalidValue;
 }
@@ -1359,6 +1367,8 @@ int gemm_tile_bn(int variant) {
     if (variant == 17) return 192;
     if (variant == 19 || variant == 20 || (variant >= 24 && variant <= 26)) return 128;
     if ((variant >= 21 && variant <= 23) || (variant >= 27 && variant <= 32)) return 64;
+    if (variant == 33 || variant == 34) return 128;
+    if (variant == 35) return 256;
     return (variant >= 0 && variant < NUM_TILE_CFGS) ? bn[variant] : 0;
 }
 

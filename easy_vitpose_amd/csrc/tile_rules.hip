@@ -74,6 +74,15 @@ Tile2Pick pick_gemm2_tile(int epi, int M, int N, int K) {
     const long t192 = (long)((M + 191) / 192) * ((N + 127) / 128) * par_;
     const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128) * par_;
     if (t192 >= 384) return tp;
+    // Round 6: a wide GEMM whose 128 x 128 tiles need a second, mostly empty round (257-384 tiles on 256 CUs) while its 192 x 128 tiles are ONE round (<= 256: M is a
+    // multiple of 192) runs on the 8-wave 192 x 128 tile with a 3-stage ring (Cfg20, one workgroup per CU) in groups of 8 m-tiles, m fastest (an XCD then owns a few
+    // weight n-tiles x all crops).  K >= 1024 only: ViTPose-B's 12 k-blocks do not amortise the deeper prologue (measured +3 %, profiles/small_batch_r5.txt call 10).
+    // ViTPose-L, 7-8 crops (one GPU's share of BASELINE configs[3]): qkv 25.6 -> 23.5 us, fc1 27.8 -> 25.5 us per layer; ViTPose-H at 8 crops: qkv only (fc1: 320 tiles).
+    if ((epi == vp::EPI_BIAS || epi == vp::EPI_BIAS_GELU) && K >= 1024 && K % 128 == 0 && M % 192 == 0 && N % 128 == 0 && t128 > 256 && t192 <= 256) {
+        tp.variant = 20;
+        tp.group_m = 8;
+        return tp;
+    }
     tp.variant = (t128 >= 256) ? 1 : 9;
     tp.group_m = 0;
     if (tp.variant == 9) {

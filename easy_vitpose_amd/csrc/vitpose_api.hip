@@ -263,7 +263,10 @@ int forward_chunk(vp_ctx* c, const void* d_crops, int fmt, int n, bool want_toke
         int tiles = 0;
         LnFuse prod; prod.plane = plane; prod.stats_out = c->ln_part; prod.tiles_out = &tiles;
         // small batches: the consumers fold the partial statistics themselves (same code, same bits) -- 2 x depth launches less
-        const bool fold_stats = n <= c->graph_max_n_stats;
+        // (round 6: not where mlp.fc1 runs on the one-round 192 x 128 tile (Cfg20: ViTPose-L at 6-8 crops) -- merging 192 rows x 16 granules in front of the K-loop of
+        // a one-workgroup-per-CU tile costs more than the two ln_finalize launches it saves: 8 crops 2.331 -> 2.259 ms, 7 crops 2.237 -> 2.181, 6 crops 2.175 -> 2.131;
+        // every other model / batch keeps the fold: profiles/small_batch_r6.txt)
+        const bool fold_stats = n <= c->graph_max_n_stats && pick_gemm2_tile(vp::EPI_BIAS_GELU, M, 4 * D, D).variant != 20;
         auto finalize = [&]() -> int {
             if (fold_stats) return VP_OK;
             LAUNCH(c, VP_PROF_LAYERNORM, 0.0, 8.0 * M * tiles + 8.0 * M, vp::ln_finalize_launch(c->ln_part, c->rowstat, M, tiles, D, c->stream));

@@ -160,31 +160,19 @@ def content_state_dict(variant: str, dataset: str):
     return shp, sd
 
 
-CONTENT_TIE = 3e-3   # a runner-up peak closer than this to the maximum of the REFERENCE's heatmap is a tie: the device's heatmaps may differ from the reference's by
+CONTENT_TIE = 3e-3   # a pixel closer than this to the maximum of the REFERENCE's heatmap is a tie: the device's heatmaps may differ from the reference's by
                      # up to ~1.6e-3 per value (fp16 operands; confidences within 1e-3 is a statement about the maximum), so either peak is a correct arg-max
 
 
-def peak_margin(heatmaps: np.ndarray, radius: int = 1) -> np.ndarray:
-    """Per joint: maximum minus the largest value OUTSIDE the (2 radius + 1)^2 neighbourhood of the arg-max -- how far the runner-up peak is below the
-    winner ("the oracle's per-joint argmax margin stored so flat/tied joints can be excluded from the +-0.5 px check").  A margin
-    below the value tolerance means the REFERENCE's own arg-max is decided by less than what `confidences within 1e-3` allows the values to differ by."""
-    n, k, H, W = heatmaps.shape
-    out = np.empty((n, k), np.float32)
-    for i in range(n):
-        for j in range(k):
-            hm = heatmaps[i, j]
-            y0, x0 = divmod(int(hm.argmax()), W)
-            m = hm.copy()
-            m[max(0, y0 - radius):y0 + radius + 1, max(0, x0 - radius):x0 + radius + 1] = -np.inf
-            out[i, j] = hm[y0, x0] - m.max()
-    return out
+CONTENT_COND_PX = 0.25   # the reference's own keypoint moves by more than this under a 3e-4 (rms) perturbation of its heatmap: ill-posed in the reference itself
 
 
 def content_coordinate_error(got_yx: np.ndarray, z, lo: int = 0) -> "tuple[np.ndarray, np.ndarray]":
-    """Per joint: distance (max over y / x, crop pixels) between the device's keypoint and the reference's -- where the reference's heatmap has a runner-up (or
-    third) peak within CONTENT_TIE of its maximum, to the NEAREST of the reference's answers: its own keypoint or the keypoint its decode gives from that peak
-    (full_content_*.npz: alt_yx / alt_margin, computed by make_golden.py with the reference's post_dark_udp + transform_preds).  No joint is exempt.
-    Returns (error [n, K], index of the matched answer [n, K]: 0 = the reference's keypoint, 1 / 2 = an alternate)."""
+    """Per joint: distance (max over y / x, crop pixels) between the device's keypoint and the reference's -- where the reference's heatmap has further pixels
+    within CONTENT_TIE of its maximum (neighbours of the arg-max or a second peak), to the NEAREST of the reference's answers: its own keypoint or the keypoint
+    its decode gives when started from one of those pixels (full_content_*.npz: alt_yx / alt_margin = the four best pixels behind the arg-max, decoded by
+    make_golden.py with the reference's post_dark_udp + transform_preds).  No joint is exempt.
+    Returns (error [n, K], index of the matched answer [n, K]: 0 = the reference's keypoint, 1 .. 4 = an alternate)."""
     n = len(got_yx)
     ref = z['keypoints'][lo:lo + n, :, :2]
     cand = np.concatenate([ref[:, :, None], z['alt_yx'][lo:lo + n]], 2)                       # [n, K, 3, 2]

@@ -356,37 +356,43 @@ def main():
             t0 = time.time()
             with torch.no_grad():
                 kps = np.concatenate([V._inference_torch(crops[i]) for i in range(n)], 0).astype(np.float32)
-                # the reference's own heatmaps once more (its pre_img + its model): a linear read-out of random features leaves a few blobs with two or three
-                # near-tied maxima 2-3 pixels apart, which the REFERENCE itself separates by less than the 1e-3 its values may differ by.
-                # Stored per joint: the margin of the runner-up and of the third peak (each outside the 3 x 3 neighbourhood of the better ones) and the
-                # keypoint the reference's own decode (post_dark_udp + transform_preds, the calls of keypoints_from_heatmaps) gives when started from them
-                from cases import peak_margin
+                # the reference's own heatmaps once more (its pre_img + its model).  A linear read-out of random features gives noisy blobs: 5-10 % of the joints
+                # have further pixels -- neighbours of the arg-max or a second maximum 2-3 pixels away -- within 3e-3 of the maximum, i.e. the REFERENCE decides
+                # its arg-max by less than its values may differ under `confidences within 1e-3`, and on such a surface the DARK step from the runner-up pixel
+                # lands up to 1 px from the step from the winner.  Stored per joint: the four best pixels behind the arg-max with their
+                # distance below the maximum, and the keypoint the reference's own decode (post_dark_udp + transform_preds, the calls keypoints_from_heatmaps
+                # makes) gives when started from each
                 from easy_ViTPose.vit_utils.top_down_eval import post_dark_udp as ref_dark
                 from easy_ViTPose.vit_utils.post_processing.post_transforms import transform_preds as ref_tp
-                K = shp.num_keypoints
-                margin = np.zeros((n, K), np.float32)
-                alt_yx = np.zeros((n, K, 2, 2), np.float32)
-                alt_margin = np.zeros((n, K, 2), np.float32)
+                K, NALT = shp.num_keypoints, 4
+                alt_yx = np.zeros((n, K, NALT, 2), np.float32)
+                alt_margin = np.zeros((n, K, NALT), np.float32)
+                cond_px = np.zeros((n, K), np.float32)
                 selfcheck = 0.0
                 for i in range(n):
                     hm = V._vit_pose(torch.from_numpy(V.pre_img(crops[i])[0])).numpy()
-                    margin[i] = peak_margin(hm)[0]
                     for k in range(K):
                         h = hm[0, k]
-                        m = h.copy()
-                        for a in range(3):          # a = 0: the arg-max itself (self-check against _inference_torch), 1 / 2: the alternates
-                            y0, x0 = divmod(int(m.argmax()), m.shape[1])
-                            c = np.array([[[x0, y0]]], dtype=np.float32)
-                            c = ref_dark(c, h[None, None].copy(), kernel=11)
+                        order = np.argsort(-h.ravel(), kind='stable')[:NALT + 1]
+                        for a, flat in enumerate(order):          # a = 0: the arg-max itself (self-check against _inference_torch)
+                            y0, x0 = divmod(int(flat), h.shape[1])
+                            c = ref_dark(np.array([[[x0, y0]]], dtype=np.float32), h[None, None].copy(), kernel=11)
                             xy = ref_tp(c[0], np.array([192 // 2, 256 // 2]), np.array([192, 256]), [48, 64], use_udp=True)[0]
                             if a == 0:
                                 selfcheck = max(selfcheck, float(np.abs(xy[::-1] - kps[i, k, :2]).max()))
                             else:
                                 alt_yx[i, k, a - 1] = xy[::-1]
                                 alt_margin[i, k, a - 1] = h.max() - h[y0, x0]
-                            m[max(0, y0 - 1):y0 + 2, max(0, x0 - 1):x0 + 2] = -np.inf
+                    # ... and how far the reference's OWN keypoints move when its heatmaps are perturbed by what `confidences within 1e-3` lets an implementation
+                    # differ by (white noise, sigma 3e-4 = the rms error of the fp16 path; 8 seeded draws through the reference's postprocess): where that
+                    # exceeds the coordinate tolerance the two tolerances of the north_star contradict each other for ANY implementation that is not
+                    # bit-identical (an isolated noise spike as arg-max, a flat top: the DARK step divides by a near-singular Hessian)
+                    rng_c = np.random.default_rng(1000 + i)
+                    base = V.postprocess(hm.copy(), 192, 256)[0, :, :2]
+                    for _ in range(8):
+                        pert = hm + rng_c.normal(0.0, 3e-4, size=hm.shape).astype(np.float32)
+                        cond_px[i] = np.maximum(cond_px[i], np.abs(V.postprocess(pert, 192, 256)[0, :, :2] - base).max(-1))
                 assert selfcheck < 1e-4, f'decode from the arg-max differs from _inference_torch by {selfcheck}'
-                assert np.abs(alt_margin[..., 0] - margin).max() < 1e-6
             # oracle-vs-reference on the first crops (the same check tests/test_oracle_golden.py repeats against the stored outputs)
             from oracle import vitpose_cpu as O
             sdt = O.to_torch_state_dict(sd)
@@ -396,10 +402,11 @@ def main():
             loc = np.hypot(kps[..., 0] - want_yx[..., 0], kps[..., 1] - want_yx[..., 1])
             print(f'content {variant}/{dataset}: {n} crops x {K} joints through the reference in {time.time() - t0:.0f} s, confidences '
                   f'{kps[..., 2].min():.3f} .. {kps[..., 2].max():.3f}, distance to the blob centres median {np.median(loc):.2f} px / p90 '
-                  f'{np.percentile(loc, 90):.2f} px, oracle-vs-reference max|d| = {np.abs(okp - kps[:4]).max():.3e}; runner-up margin < 2e-3 on '
-                  f'{int((margin < 2e-3).sum())} of {margin.size} joints (min {margin.min():.2e}, median {np.median(margin):.3f})', flush=True)
+                  f'{np.percentile(loc, 90):.2f} px, oracle-vs-reference max|d| = {np.abs(okp - kps[:4]).max():.3e}; runner-up pixel within 3e-3 of the maximum on '
+                  f'{int((alt_margin[..., 0] < 3e-3).sum())} of {alt_margin[..., 0].size} joints (min {alt_margin[..., 0].min():.2e}); the reference '
+                  f'moves its own keypoint by > 0.25 px under a 3e-4 heatmap perturbation on {int((cond_px > 0.25).sum())} joints (max {cond_px.max():.2f} px)', flush=True)
             np.savez_compressed(os.path.join(HERE, f'full_content_{variant}_{dataset}.npz'), variant=variant, dataset=dataset, n=n, keypoints=kps,
-                                blobs=blobs.astype(np.float32), margin=margin.astype(np.float32), alt_yx=alt_yx, alt_margin=alt_margin)
+                                blobs=blobs.astype(np.float32), alt_yx=alt_yx, alt_margin=alt_margin, cond_px=cond_px)
 
 
 if __name__ == '__main__':

@@ -375,6 +375,7 @@ def test_every_tile_choice_of_the_selection_rule_is_bit_identical():
 _C31, _C30, _C12, _C15 = '<32, 64, 64, 16, 32, 6, 6', '<64, 64, 64, 32, 32, 6, 6', '<64, 64, 64, 32, 32, 4, 0', '<128, 64, 64, 64, 32, 3, 0'
 
 
+@pytest.mark.usefixtures('one_launch_family')
 @pytest.mark.parametrize('variant,dataset,cases', [
     ('b', 'coco', [(1, _C31, _C31), (4, _C30, _C30), (12, _C12, _C12), (16, _C15, _C15), (24, _C15, _C15)]),
     ('l', 'coco_25', [(2, _C31, _C31), (12, _C15, _C15)]),

@@ -229,6 +229,7 @@ def test_tokens_tap_and_input_formats():
     eng.close()
 
 
+@pytest.mark.usefixtures('one_launch_family')
 def test_batching_edge_cases():
     """empty batch, batch 1, ragged chunking over max_batch, determinism, batch invariance."""
     shp, sd, _ = weights('s', 'coco')
@@ -257,6 +258,7 @@ def test_state_dict_errors():
         VitPoseHip(shp, bad, max_batch=1)
 
 
+@pytest.mark.usefixtures('one_launch_family')
 def test_baseline_batch_properties():
     """ViTPose-B, batch 256 (BASELINE config 2): crop i of the big batch == crop i alone;
     spot parity of 4 crops against the oracle."""
@@ -279,6 +281,7 @@ def test_baseline_batch_properties():
     eng.close()
 
 
+@pytest.mark.usefixtures('one_launch_family')
 def test_config5_ap10k_batch512_workload():
     """BASELINE configs[4]'s WORKLOAD -- ViTPose-B / AP-10K (17 animal joints, configs/ViTPose_ap10k.py:4-22), batch 512 on one
     GPU -- through the shipped fp16 path (its fp8 operands are tolerance-infeasible: DESIGN.md section 6, confirmed on the hardware by
@@ -341,6 +344,7 @@ def test_persistent_gemm_is_bit_identical(monkeypatch):
 
 
 # ------------------------------------------------------------------- VitInference API
+@pytest.mark.usefixtures('one_launch_family')
 def test_vitinference_surface_with_fake_detector():
     shp, sd, sdt = weights('s', 'coco')
     frame = np.zeros((480, 640, 3), np.uint8)

@@ -188,7 +188,7 @@ def test_split_k_rule_over_every_batch_size():
 
 
 def test_gemm2_tile_selection_over_every_batch_size():
-    """The rule that picks the 2-phase kernel's tile configuration (vitpose_api.hip pick_gemm2_tile, through the host-only tap vp_dbg_gemm2_pick) walked over every
+    """The rule that picks the 2-phase kernel's tile configuration (tile_rules.hip pick_gemm2_tile, through the host-only tap vp_dbg_gemm2_pick) walked over every
     batch size 1..400 of every model and every GEMM of the path.  Invariants: only configurations the PRODUCT library instantiates; the deep rings (4-stage 64 x 64,
     3-stage 128 x 64, the two-k-blocks-per-barrier configurations) only where ALL their tiles are resident at once (one round) -- except the round-2 long-K case --;
     two k-blocks per barrier only for an even number of k-blocks; the default 192 x 128 tile from 384 tiles on; and the operating points measured in round 5
@@ -197,7 +197,7 @@ def test_gemm2_tile_selection_over_every_batch_size():
     gm = C.c_int32()
     # Cfg id -> (BM, BN, resident workgroups on 256 CUs, two k-blocks per barrier)
     cfgs = {8: (192, 128, 512, False), 11: (192, 128, 512, False), 1: (128, 128, 512, False), 9: (64, 64, 1280, False), 12: (64, 64, 512, False),
-            15: (128, 64, 512, False), 30: (64, 64, 256, True), 31: (32, 64, 512, True)}
+            15: (128, 64, 512, False), 30: (64, 64, 256, True), 31: (32, 64, 512, True), 20: (192, 128, 256, False)}
 
     def pick(epi, M, N, K):
         v = lib.vp_dbg_gemm2_pick(epi, M, N, K, C.byref(gm))
@@ -217,7 +217,9 @@ def test_gemm2_tile_selection_over_every_batch_size():
                 if t192 >= 384:
                     assert v == (11 if epi == 6 else 8) and g == (8 if epi in (0, 1) else 0), (D, n, epi, v, g)
                     continue
-                assert v not in (8, 11) and g == 0
+                assert v not in (8, 11) and g == (8 if v == 20 else 0)
+                if v == 20:   # round 6: one round of 192 x 128 tiles where 128 x 128 tiles would need a second, mostly empty one
+                    assert epi in (0, 1) and K >= 1024 and tiles <= 256 and -(-m // 128) * -(-N // 128) > 256 and m % 192 == 0
                 if v == 1:
                     assert tiles >= 256
                 if v in (15, 30, 31) or (v == 12 and K < 2048):
@@ -235,7 +237,8 @@ def test_gemm2_tile_selection_over_every_batch_size():
     # operating points of round 5 (in situ, profiles/small_batch_r5.txt): (qkv, fc1, proj, fc2)
     enc = lambda D, n: tuple(pick(e, 192 * n, N, K)[0] for e, N, K in ((0, 3 * D, D), (1, 4 * D, D), (6, D, D), (6, D, 4 * D)))
     assert enc(1024, 1) == (30, 30, 31, 31) and enc(1024, 2) == (12, 12, 31, 31) and enc(1024, 4) == (9, 9, 30, 30)      # ViTPose-L
-    assert enc(1024, 8) == (1, 1, 12, 12) and enc(1024, 12) == (1, 8, 15, 15) and enc(1024, 16)[2:] == (15, 15) and enc(1024, 24)[2:] == (1, 1)
+    assert enc(1024, 8) == (20, 20, 12, 12) and enc(1024, 7)[:2] == (20, 20) and enc(1280, 8)[:2] == (20, 1) and enc(1024, 6)[:2] == (9, 20)   # round 6: one round of 192 x 128 tiles
+    assert enc(1024, 12) == (1, 8, 15, 15) and enc(1024, 16)[2:] == (15, 15) and enc(1024, 24)[2:] == (1, 1)
     assert enc(768, 1) == (31, 30, 31, 31) and enc(768, 4) == (12, 9, 30, 30) and enc(768, 8) == (9, 1, 12, 12)          # ViTPose-B
     assert enc(768, 12)[2:] == (12, 12) and enc(768, 16)[2:] == (15, 15) and enc(768, 24)[2:] == (15, 15) and enc(768, 32)[2:] == (1, 1)
     assert enc(1280, 1) == (30, 30, 31, 31) and enc(1280, 4)[2:] == (30, 30) and enc(1280, 8)[2:] == (12, 12) and enc(1280, 12)[2:] == (15, 15)   # ViTPose-H
@@ -244,7 +247,7 @@ def test_gemm2_tile_selection_over_every_batch_size():
 
 
 def test_gemm8_tile_selection_over_every_batch_size():
-    """The rule that picks the 8-phase kernel's tile (vitpose_api.hip pick_gemm8_tile, through the host-only tap vp_dbg_gemm8_pick) walked over every
+    """The rule that picks the 8-phase kernel's tile (tile_rules.hip pick_gemm8_tile, through the host-only tap vp_dbg_gemm8_pick) walked over every
     batch size 1..640 of every model.  Invariants: a picked tile divides the matrix and the tap reports its tile count; the wide GEMMs never get the
     192-column tile; the mask bits switch the 192-row tile off per GEMM kind; a pick is justified -- it fills its rounds (>= 448 tiles, >= 192 with a last
     round >= 80 % full, or one round from 192 tiles) or it needs fewer rounds x tile area than the 2-phase kernel; nothing is picked below 192 tiles;

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Which tile should fc1 / fc2 run on at a given batch size?  Times every candidate configuration of the two MLP GEMMs in isolation (vp_dbg_gemm_bench2: production
 epilogues and layouts, random operands) over a list of batch sizes and prints, per shape, the launch time of each candidate and what the selection rule of
-vitpose_api.hip (vp_dbg_gemm8_pick) would pick -- the data behind the rule's thresholds (profiles/tile_sweep_r4.txt).  GPU box only.
+tile_rules.hip (vp_dbg_gemm8_pick) would pick -- the data behind the rule's thresholds (profiles/tile_sweep_r4.txt).  GPU box only.
 
     python tools/tile_sweep.py [--variant b] [--batches 40,52,...]
 """
