@@ -271,7 +271,7 @@ def strong_scaling_config4(world, rank, dev, dtype, steps=100, warmup=10, n_tota
             'persons_per_sec': round(N * steps / dt, 1), 'keypoints': kp}
 
 
-PMC_FILE = os.path.join('profiles', 'pmc_r5.json')
+PMC_FILE = os.path.join('profiles', 'pmc_r6.json')
 
 
 def pmc_traffic(args, kernel_name):

@@ -1237,11 +1237,8 @@ using Cfg29 = TileCfg<64, 64, 64, 32, 32, 4, 6, 0>;     //  64 KiB   4   (2 bloc
 using Cfg30 = TileCfg<64, 64, 64, 32, 32, 6, 6, 0>;     //  96 KiB   4   (1 block / CU)   ... 6-stage ring (4 in flight)
 using Cfg31 = TileCfg<32, 64, 64, 16, 32, 6, 6, 0>;     //  72 KiB   4   (2 blocks / CU)  32(m) x 64(n): twice the workgroups of a 1-2 crop GEMM, half the MFMAs per wave and k-block
 using Cfg32 = TileCfg<32, 64, 64, 16, 32, 8, 6, 0>;     //  96 KiB   4   (1 block / CU)   ... 8-stage ring (6 in flight)
-// round 6: the staggered two-group schedule (PIPE 3: waves 0-3 / 4-7 one barrier apart -- one group's fragment reads and DMA run beside the other group's MFMAs) on tiles a
-// few crops fill: the one-barrier-per-k-block loop spends 80 % of a Cfg20 launch in its own schedule (LDS reads and MFMAs never overlap across waves; profiles/small_batch_r6.txt call 6)
-using Cfg33 = TileCfg<256, 128, 32, 64, 64, 4, 3, 0>;   //  96 KiB   8   (1 block / CU)   256(m) x 128(n), k-blocks of 32, 4-stage ring
-using Cfg34 = TileCfg<128, 128, 32, 32, 64, 4, 3, 0>;   //  64 KiB   8   (2 blocks / CU)  128 x 128
-using Cfg35 = TileCfg<128, 256, 32, 32, 128, 4, 3, 0>;  //  96 KiB   8   (1 block / CU)   128(m) x 256(n)
+// (round 6: the staggered two-group schedule -- PIPE 3, waves 0-3 / 4-7 one barrier apart -- on 256 x 128 / 128 x 128 / 128 x 256 tiles with k-blocks of 32 was measured for the
+// 8-crop wide GEMMs and lost everywhere, +8 ... +25 % per step: profiles/small_batch_r6.txt call 9; the configurations are not kept.)
 
 template <class T, int EPI, int AMODE, class C>
 static hipError_t launch(const GemmArgs& a, hipStream_t s) {
@@ -1319,9 +1316,6 @@ static hipError_t by_variant(const GemmArgs& a, hipStream_t s) {
         case 30: return launch<T, EPI, AMODE, Cfg30>(a, s);
         case 31: return launch<T, EPI, AMODE, Cfg31>(a, s);
         VP_TOOLS_CASE(32)
-        VP_TOOLS_CASE(33)
-        VP_TOOLS_CASE(34)
-        VP_TOOLS_CASE(35)
     }
     return hipErrorInvalidValue;
 }
@@ -1367,8 +1361,6 @@ int gemm_tile_bn(int variant) {
     if (variant == 17) return 192;
     if (variant == 19 || variant == 20 || (variant >= 24 && variant <= 26)) return 128;
     if ((variant >= 21 && variant <= 23) || (variant >= 27 && variant <= 32)) return 64;
-    if (variant == 33 || variant == 34) return 128;
-    if (variant == 35) return 256;
     return (variant >= 0 && variant < NUM_TILE_CFGS) ? bn[variant] : 0;
 }
 
