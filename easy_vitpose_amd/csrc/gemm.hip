@@ -1238,7 +1238,8 @@ using Cfg30 = TileCfg<64, 64, 64, 32, 32, 6, 6, 0>;     //  96 KiB   4   (1 bloc
 using Cfg31 = TileCfg<32, 64, 64, 16, 32, 6, 6, 0>;     //  72 KiB   4   (2 blocks / CU)  32(m) x 64(n): twice the workgroups of a 1-2 crop GEMM, half the MFMAs per wave and k-block
 using Cfg32 = TileCfg<32, 64, 64, 16, 32, 8, 6, 0>;     //  96 KiB   4   (1 block / CU)   ... 8-stage ring (6 in flight)
 // (round 6: the staggered two-group schedule -- PIPE 3, waves 0-3 / 4-7 one barrier apart -- on 256 x 128 / 128 x 128 / 128 x 256 tiles with k-blocks of 32 was measured for the
-// 8-crop wide GEMMs and lost everywhere, +8 ... +25 % per step: profiles/small_batch_r6.txt call 9; the configurations are not kept.)
+// 8-crop wide GEMMs and lost everywhere, +8 ... +25 % per step, as did register double-buffered fragments -- PIPE 2 -- on 192 x 128 / 128 x 128 / 128 x 64 / 64 x 64 tiles with k-blocks of 32,
+// +3 ... +20 %: profiles/small_batch_r6.txt calls 9-10; the configurations are not kept.)
 
 template <class T, int EPI, int AMODE, class C>
 static hipError_t launch(const GemmArgs& a, hipStream_t s) {
