@@ -123,7 +123,12 @@ VP_API int vp_load_weights(vp_handle h, const vp_tensor_desc* tensors, int32_t n
 /* The hot path on host buffers: H2D crops, model, decode, D2H keypoints; returns
  * when `out` is complete.  Batched replacement of `_inference_torch`
  * (inference.py:320-328).  org_wh = N x (org_w, org_h) int32 of each crop before
- * pre_img's resize (NULL = 192x256 for all); out = float32 [N, K, 3] (y, x, conf). */
+ * pre_img's resize (NULL = 192x256 for all); out = float32 [N, K, 3] (y, x, conf).
+ * Numerics contract: every call is run-to-run bit-identical (no atomics anywhere) and within the parity tolerances of the
+ * reference (+-0.5 px, confidences 1e-3).  Equal BITS for a crop at every batch size hold inside the one-launch kernel family;
+ * a chunk of one or two crops (ViTPose-H: also seven or eight) runs mlp.fc2 as four k ranges + a fixed-order reduction (a
+ * different fp32 accumulation order), so such a call differs from the same crop inside a larger batch in the last bits.
+ * VP_SPLITK=0 (read at vp_create) pins a handle to the one-launch family. */
 VP_API int vp_infer(vp_handle h, const void* crops, int32_t input_format, int32_t n,
              const int32_t* org_wh, float* out);
 
