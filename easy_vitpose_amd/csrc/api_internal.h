@@ -108,6 +108,7 @@ struct vp_ctx {
                                       // themselves (once per row and tile, in the prologue: gemm.hip) and the 2 x depth ln_finalize launches disappear -- same
                                       // ln_merge, bit-identical.  Measured (profiles/fold_stats_r3.txt): -7...-12 % per step at 1-8 crops, +0...+20 % at
                                       // 16-48 (every column tile merges its rows again): threshold 8.  VP_FOLD_STATS=n moves it (0 = always ln_finalize).
+                                      // Round 6 (merge on a register copy, profiles/small_batch_r6.txt call 11): -2.6 ... -6.5 % against ln_finalize at 1-8 crops.
                                       // Round 2 merged per LANE in the epilogue (16 x redundant): slower than ln_finalize even at 8 crops (3.89 vs 2.97 ms).
     // split-K for the residual GEMMs of small batches (round 6; tile_rules.hip pick_splitk, gemm.hip EPI_PARTIAL, elementwise.hip splitk_reduce_kernel): fp32 partial
     // products [S][M][D] of up to splitk_rows token rows.  VP_SPLITK=0 switches it off (the parity test flips it); VP_SPLITK="fc2:S:variant,proj:S:variant" overrides the rule.

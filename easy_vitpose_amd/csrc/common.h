@@ -111,6 +111,21 @@ __device__ __forceinline__ void ln_merge(const float* __restrict__ p, int tiles,
     rstd = rsqrtf(__builtin_fmaf(m2, inv_d, 1e-6f));
 }
 
+// The same merge on a REGISTER copy of the row's TILES granule statistics, fetched up front as TILES / 2 loads of 16 bytes (one memory latency instead of 2 x TILES dependent
+// 4-byte loads): what ln_finalize_kernel_t and the consumer GEMMs' prologue (gemm.hip, GemmArgs::ln_part) run.  ln_merge on the copy: identical operations, identical bits.
+template <int TILES>
+__device__ __forceinline__ void ln_merge_row(const float* __restrict__ p, float inv_d, float& mean, float& rstd) {
+    static_assert(TILES % 2 == 0, "a row of partials is a whole number of 16-byte pieces");
+    const f32x4* src = (const f32x4*)p;
+    float v[2 * TILES];
+#pragma unroll
+    for (int i = 0; i < TILES / 2; ++i) {
+        const f32x4 q = src[i];
+        v[4 * i] = q[0]; v[4 * i + 1] = q[1]; v[4 * i + 2] = q[2]; v[4 * i + 3] = q[3];
+    }
+    ln_merge(v, TILES, inv_d, mean, rstd);
+}
+
 // softmax numerator 2^(s scale - mb) with the multiply-add as ONE explicit fma: under -ffp-contract=fast hipcc fuses `s * scale - mb` for most
 // elements and emits v_pk_mul + v_sub for a few, and WHICH ones depends on the surrounding code -- attention.hip and qkvattn.hip then differed in
 // the last bit of ~1 % of the probabilities (round 4).  One definition, one rounding, for every kernel that must agree bit for bit.

@@ -403,22 +403,27 @@ __global__ __launch_bounds__(C::NT, 2) void gemm_kernel(GemmArgs g) {
     if constexpr (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) {
         // Fused LayerNorm at small batch (GemmArgs::ln_part): the tile's BM rows are merged ONCE, one row per thread, and shared through LDS
         // behind the operand ring -- not once per lane and fragment row in the epilogue (16 x redundant, round 2: slower than the separate
-        // ln_finalize launch it replaced).  The tile's block of partial statistics ([BM][ln_tiles][2] floats, contiguous) comes in by
-        // LDS-DMA into the ring slot the prologue leaves free (slot STAGES-1 is first written after the K-loop's first barrier), next to the
-        // first k-blocks; one thread per row then runs ln_merge on it -- the same code ln_finalize_kernel runs: same bits.
+        // ln_finalize launch it replaced).  Round 6: a thread fetches its row's granule statistics straight from L2 into registers -- ln_tiles / 2
+        // loads of 16 bytes, issued beside the first k-blocks -- and runs ln_merge on the register copy: the code of ln_finalize_kernel_t, the same
+        // operations in the same order, hence the same bits.  (Rounds 3-5 DMA'd the tile's block of partials into a free ring slot and merged from
+        // LDS: rows of ln_tiles * 8 = 96 / 128 / 160 bytes put every thread's reads on the same few banks -- up to 32-way conflicts at D = 1024 --
+        // and the merge needed its own vmcnt(0) + barrier in front of the K-loop: with the 192-row one-round tiles the two ln_finalize launches
+        // were cheaper than that; profiles/small_batch_r6.txt calls 7-8 and 11.)  (mean, rstd) land behind the ring; the first reader is the
+        // epilogue, behind its own barrier.
         if (g.ln_part) {
-            char* pb = smem + (C::STAGES - 1) * C::STAGE_BYTES;
-            const int row_bytes = g.ln_tiles * 8;
-            const int valid = min(C::BM, g.M - m0) * row_bytes;            // rows past M are never stored: left as they are
-            const char* src = (const char*)(g.ln_part + (size_t)m0 * g.ln_tiles * 2);
-            for (int i = wave * 1024; i < C::BM * row_bytes; i += C::NWAVES * 1024)
-                if (i + lane * 16 < valid) glds16(src + i + lane * 16, pb + i);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
             float2* st = (float2*)(smem + C::LDS);
             for (int r = tid; r < C::BM; r += C::NT) {
-                float mean, rstd;
-                ln_merge((const float*)(pb + r * row_bytes), g.ln_tiles, g.ln_inv_d, mean, rstd);
+                int m = m0 + r;
+                if (m > g.M - 1) m = g.M - 1;                                  // rows past M are never stored
+                const float* src = g.ln_part + (size_t)m * g.ln_tiles * 2;
+                float mean = 0.f, rstd = 1.f;
+                switch (g.ln_tiles) {
+                    case 6: ln_merge_row<6>(src, g.ln_inv_d, mean, rstd); break;
+                    case 12: ln_merge_row<12>(src, g.ln_inv_d, mean, rstd); break;
+                    case 16: ln_merge_row<16>(src, g.ln_inv_d, mean, rstd); break;
+                    case 20: ln_merge_row<20>(src, g.ln_inv_d, mean, rstd); break;
+                    default: ln_merge(src, g.ln_tiles, g.ln_inv_d, mean, rstd);
+                }
                 st[r] = float2{mean, rstd};
             }
         }
@@ -1251,8 +1256,7 @@ static hipError_t launch(const GemmArgs& a, hipStream_t s) {
     static_assert(LDS_BYTES + LN_STAT_BYTES <= 160 * 1024, "LDS");
     if (a.ln_part && (C::PIPE == 2 || C::PIPE == 3 || C::DIRECT)) return hipErrorInvalidValue;   // the prologue merge lives in the generic loop
     if (C::PIPE == 6 && a.K % 128 != 0) return hipErrorInvalidValue;                                      // two k-blocks per barrier
-    if (a.ln_part && C::BM * a.ln_tiles * 8 > C::STAGE_BYTES) return hipErrorInvalidValue;                  // ... and borrows one ring slot
-    if (a.ln_part && (a.ln_tiles & 1)) return hipErrorInvalidValue;   // the block of partial statistics is DMA'd in 16-byte pieces: rows of ln_tiles * 8 bytes must be 16-byte multiples
+    if (a.ln_part && (a.ln_tiles & 1)) return hipErrorInvalidValue;   // a row's partial statistics are fetched as 16-byte pieces: ln_tiles * 8 bytes must be a multiple of 16
     static bool attr_done[64] = {};   // the > 64 KiB LDS opt-in is a per-device function attribute
     int dev = 0;
     (void)hipGetDevice(&dev);

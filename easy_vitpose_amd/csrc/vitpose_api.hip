@@ -263,10 +263,11 @@ int forward_chunk(vp_ctx* c, const void* d_crops, int fmt, int n, bool want_toke
         int tiles = 0;
         LnFuse prod; prod.plane = plane; prod.stats_out = c->ln_part; prod.tiles_out = &tiles;
         // small batches: the consumers fold the partial statistics themselves (same code, same bits) -- 2 x depth launches less
-        // (round 6: not where mlp.fc1 runs on the one-round 192 x 128 tile (Cfg20: ViTPose-L at 6-8 crops) -- merging 192 rows x 16 granules in front of the K-loop of
-        // a one-workgroup-per-CU tile costs more than the two ln_finalize launches it saves: 8 crops 2.331 -> 2.259 ms, 7 crops 2.237 -> 2.181, 6 crops 2.175 -> 2.131;
-        // every other model / batch keeps the fold: profiles/small_batch_r6.txt)
-        const bool fold_stats = n <= c->graph_max_n_stats && pick_gemm2_tile(vp::EPI_BIAS_GELU, M, 4 * D, D).variant != 20;
+        // (round 6: with the consumers' merge on a register copy of the row's statistics instead of a bank-conflicted LDS image -- gemm.hip, GemmArgs::ln_part -- the fold wins at
+        // every model and batch up to 8 crops, the one-round 192 x 128 tiles of ViTPose-L included: 8 crops 2.200 -> 2.143 ms against the ln_finalize launches, 4 crops 1.874 ->
+        // 1.800, 1 crop 1.172 -> 1.111; beyond 8 crops it still loses (every column tile merges its rows again; ViTPose-H's fused qkv + attention tile needs rowstat):
+        // profiles/small_batch_r6.txt call 11)
+        const bool fold_stats = n <= c->graph_max_n_stats;
         auto finalize = [&]() -> int {
             if (fold_stats) return VP_OK;
             LAUNCH(c, VP_PROF_LAYERNORM, 0.0, 8.0 * M * tiles + 8.0 * M, vp::ln_finalize_launch(c->ln_part, c->rowstat, M, tiles, D, c->stream));
