@@ -1242,9 +1242,12 @@ using Cfg29 = TileCfg<64, 64, 64, 32, 32, 4, 6, 0>;     //  64 KiB   4   (2 bloc
 using Cfg30 = TileCfg<64, 64, 64, 32, 32, 6, 6, 0>;     //  96 KiB   4   (1 block / CU)   ... 6-stage ring (4 in flight)
 using Cfg31 = TileCfg<32, 64, 64, 16, 32, 6, 6, 0>;     //  72 KiB   4   (2 blocks / CU)  32(m) x 64(n): twice the workgroups of a 1-2 crop GEMM, half the MFMAs per wave and k-block
 using Cfg32 = TileCfg<32, 64, 64, 16, 32, 8, 6, 0>;     //  96 KiB   4   (1 block / CU)   ... 8-stage ring (6 in flight)
+using Cfg41 = TileCfg<96, 64, 64, 48, 32, 4, 0, 0>;     //  80 KiB   4   (2 blocks / CU)  96(m) x 64(n), 4-stage ring: the residual GEMMs between the 64 x 64 and 128 x 64 regimes (round 6: <= 448 tiles;
+                                                        //                                 ViTPose-L 11-14 crops, -B 15-18, -H 9-11: profiles/small_batch_r6.txt call 18)
 // (round 6: the staggered two-group schedule -- PIPE 3, waves 0-3 / 4-7 one barrier apart -- on 256 x 128 / 128 x 128 / 128 x 256 tiles with k-blocks of 32 was measured for the
 // 8-crop wide GEMMs and lost everywhere, +8 ... +25 % per step, as did register double-buffered fragments -- PIPE 2 -- on 192 x 128 / 128 x 128 / 128 x 64 / 64 x 64 tiles with k-blocks of 32,
-// +3 ... +20 %: profiles/small_batch_r6.txt calls 9-10; the configurations are not kept.)
+// +3 ... +20 %: profiles/small_batch_r6.txt calls 9-10; the configurations are not kept.  Also measured and not kept (calls 13, 15): a 4-stage ring on the one-round
+// 192 x 128 tile (+1 %), the 96 x 64 tile with a 6-stage ring / two k-blocks per barrier (loses wherever the 4-stage one wins).)
 
 template <class T, int EPI, int AMODE, class C>
 static hipError_t launch(const GemmArgs& a, hipStream_t s) {
@@ -1281,7 +1284,7 @@ static hipError_t launch(const GemmArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
-// the product library carries the configurations the selection rule of tile_rules.hip can pick (1, 3, 8, 9, 11, 12, 15, 20, 30, 31);
+// the product library carries the configurations the selection rule of tile_rules.hip can pick (1, 3, 8, 9, 11, 12, 15, 20, 30, 31, 41);
 // the measured alternatives are instantiated in the VP_TOOLS build only
 #ifdef VP_TOOLS
 #define VP_TOOLS_CASE(v) case v: return launch<T, EPI, AMODE, Cfg##v>(a, s);
@@ -1321,6 +1324,7 @@ static hipError_t by_variant(const GemmArgs& a, hipStream_t s) {
         case 30: return launch<T, EPI, AMODE, Cfg30>(a, s);
         case 31: return launch<T, EPI, AMODE, Cfg31>(a, s);
         VP_TOOLS_CASE(32)
+        case 41: return launch<T, EPI, AMODE, Cfg41>(a, s);
     }
     return hipErrorInvalidValue;
 }
@@ -1365,7 +1369,7 @@ int gemm_tile_bn(int variant) {
     if (variant == 16 || variant == 18) return 256;
     if (variant == 17) return 192;
     if (variant == 19 || variant == 20 || (variant >= 24 && variant <= 26)) return 128;
-    if ((variant >= 21 && variant <= 23) || (variant >= 27 && variant <= 32)) return 64;
+    if ((variant >= 21 && variant <= 23) || (variant >= 27 && variant <= 32) || variant == 41) return 64;
     return (variant >= 0 && variant < NUM_TILE_CFGS) ? bn[variant] : 0;
 }
 

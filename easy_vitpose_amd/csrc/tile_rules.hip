@@ -73,7 +73,17 @@ Tile2Pick pick_gemm2_tile(int epi, int M, int N, int K) {
     const long par_ = (epi == vp::EPI_DECONV) ? 4 : 1;   // the four output parities of a deconv are four GEMMs of one launch
     const long t192 = (long)((M + 191) / 192) * ((N + 127) / 128) * par_;
     const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128) * par_;
-    if (t192 >= 384) return tp;
+    const bool wide = epi == vp::EPI_BIAS || epi == vp::EPI_BIAS_GELU;
+    if (t192 >= 384) {
+        // Round 6 (profiles/small_batch_r6.txt call 18): more than 512 tiles of 192 x 128 are a second, mostly empty round of the 2 workgroups per CU; while 256 x 256 tiles
+        // (ragged last m-tile) are still ONE round of 256, the 2-phase 256 x 256 tile runs the wide GEMM where the 8-phase kernel has no tile for the row count:
+        // ViTPose-L 17-21 crops mlp.fc1 48.5 -> 38.5 us (step -9 ... -10.7 %), -B 22-27 crops 40 -> 33-35 us (-5 ... -7 %); bit-identical (same k order).
+        if (wide && t192 > 512 && K >= 768 && K % 128 == 0 && N % 256 == 0 && (long)((M + 255) / 256) * (N / 256) <= 256) {
+            tp.variant = 3;
+            tp.group_m = 8;
+        }
+        return tp;
+    }
     // Round 6: a wide GEMM whose 128 x 128 tiles need a second, mostly empty round (257-384 tiles on 256 CUs) while its 192 x 128 tiles are ONE round (<= 256: M is a
     // multiple of 192) runs on the 8-wave 192 x 128 tile with a 3-stage ring (Cfg20, one workgroup per CU) in groups of 8 m-tiles, m fastest (an XCD then owns a few
     // weight n-tiles x all crops).  K >= 1024 only: ViTPose-B's 12 k-blocks do not amortise the deeper prologue (measured +3 %, profiles/small_batch_r5.txt call 10).
@@ -83,12 +93,26 @@ Tile2Pick pick_gemm2_tile(int epi, int M, int N, int K) {
         tp.group_m = 8;
         return tp;
     }
+    // Round 6 (calls 18-19): 128 x 128 tiles beyond the 512 slots of 2 workgroups per CU while 192 x 128 tiles fit them: the default tile (ViTPose-L 11 crops fc1 37.9 -> 30.3 us,
+    // -B 15 crops 31.8 -> 26.6, -S 40 crops qkv 20.8 -> 17.4; the residual GEMMs of ViTPose-L 43-47 / -B 58-63 / -H 35-38 crops: fc2 118 -> 92 / 95 -> 74 / 146 -> 114 us, step -11 %)
+    if ((wide || epi == vp::EPI_BIAS_RESID_LN) && t128 > 512) return tp;
+    const long t64 = (long)((M + 63) / 64) * ((N + 63) / 64) * par_;
+    const long t128x64 = (long)((M + 127) / 128) * ((N + 63) / 64) * par_;
+    if (epi == vp::EPI_BIAS_RESID_LN && t64 > 512) {
+        // residual GEMMs beyond the 512 resident 64 x 64 tiles (round 5: 128 x 64 on a 3-stage ring up to 512 tiles, then 128 x 128).  Round 6 (call 18, all bit-identical):
+        //   * 96(m) x 64(n) tiles (Cfg41, 4-stage ring, 2 workgroups per CU) up to 448 of them: ViTPose-L 11-14 crops fc2 41-42 -> 36-38 us, proj 18.5 -> 16.4 (step -3.7 ... -4.9 %),
+        //     -B 15-16 crops -4 ... -5.6 %; at 480-512 tiles it loses (-L 16 crops 44 -> 49 us, -B 20 crops +1.8 %);
+        //   * beyond 512 tiles of 128 x 64 the 128 x 128 tile ran one workgroup per CU on a 2-stage ring (fc2 of ViTPose-L 21-32 crops flat at 66-72 us): the 8-wave 192 x 128 tile
+        //     on a 3-stage ring (Cfg20), one round of <= 256 tiles, 60-64 us, proj 27-29.5 -> 25-27: ViTPose-L 24 / 28 / 32 crops -5.5 / -5.6 / -4.9 %, -B 29 / 32 / 34 crops -4.9 / -4.5 / -4.9 %.
+        const long t96x64 = (long)((M + 95) / 96) * ((N + 63) / 64);
+        tp.group_m = 0;
+        tp.variant = t96x64 <= 448 ? 41 : t128x64 <= 512 ? 15 : (t192 <= 256 && K % 128 == 0) ? 20 : 1;
+        return tp;
+    }
     tp.variant = (t128 >= 256) ? 1 : 9;
     tp.group_m = 0;
     if (tp.variant == 9) {
-        const long t64 = (long)((M + 63) / 64) * ((N + 63) / 64) * par_;
         const long t32 = (long)((M + 31) / 32) * ((N + 63) / 64) * par_;
-        const long t128x64 = (long)((M + 127) / 128) * ((N + 63) / 64) * par_;
         if (K % 128 == 0 && t32 <= 256) tp.variant = 31;
         else if (K % 128 == 0 && t64 <= 256) tp.variant = 30;
         else if (t64 <= 512) tp.variant = 12;

@@ -279,8 +279,10 @@ int forward_chunk(vp_ctx* c, const void* d_crops, int fmt, int n, bool want_toke
             const Block& b = c->blocks[l];
             LnFuse cq; cq.rowstat = c->rowstat; cq.ln_s = b.s_qkv; cq.reverse = (c->order_mask & 1) != 0; cq.out_blocked = qkv_blocked;
             if (fold_stats) { cq.rowstat = nullptr; cq.ln_part = c->ln_part; cq.ln_tiles = D / 64; }
-            // attn.qkv + attention core as ONE kernel per (pair of crops, head) from 128 tiles on (qkvattn.hip; bit-identical y; an odd batch's last crop fills both halves of its pair)
-            static const long qa_min_tiles = [] { const char* e = getenv("VP_QA_MIN_TILES"); return e ? atol(e) : 128L; }();   // the fused kernel wins from 128 tiles on (measured sweep 128 - 1536 tiles: profiles/qkvattn_r4.txt)
+            // attn.qkv + attention core as ONE kernel per (pair of crops, head) from 108 tiles on (qkvattn.hip; bit-identical y; an odd batch's last crop fills both halves of its pair)
+            // 128 - 1536 tiles: profiles/qkvattn_r4.txt.  Below (round 6, profiles/small_batch_r6.txt call 16): 108-120 tiles win or tie (ViTPose-B 17-20 crops -0.6 ... -6.5 %: at 19-20
+            // crops the unfused qkv is 540 tiles of 128 x 128 on 512 slots; ViTPose-L 13-14 crops equal); 96 tiles and fewer lose (-B 16 crops +-0, 12 crops +3 %, -L 9-12 crops +2 ... +7 %)
+            static const long qa_min_tiles = [] { const char* e = getenv("VP_QA_MIN_TILES"); return e ? atol(e) : 108L; }();
             vp::QkvAttnArgs qa{};
             qa.x_hi = xh; qa.wh = b.w_qkvh; qa.bh = b.b_qkvh; qa.sh = b.s_qkvh; qa.rowstat = c->rowstat; qa.y = c->y;
             qa.npairs = (n + 1) / 2; qa.ncrops = n; qa.heads = c->heads; qa.D = D;   // odd n: the last crop fills both halves of its pair

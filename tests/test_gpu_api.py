@@ -373,32 +373,36 @@ def test_every_tile_choice_of_the_selection_rule_is_bit_identical():
 
 
 _C31, _C30, _C12, _C15 = '<32, 64, 64, 16, 32, 6, 6', '<64, 64, 64, 32, 32, 6, 6', '<64, 64, 64, 32, 32, 4, 0', '<128, 64, 64, 64, 32, 3, 0'
+_C41, _C20, _C3, _C8 = '<96, 64, 64, 48, 32, 4, 0', '<192, 128, 64, 48, 64, 3, 1', '<256, 256, 64, 128, 64, 2, 1', '<192, 128, 64, 96, 64, 2, 1'
 
 
 @pytest.mark.usefixtures('one_launch_family')
 @pytest.mark.parametrize('variant,dataset,cases', [
-    ('b', 'coco', [(1, _C31, _C31), (4, _C30, _C30), (12, _C12, _C12), (16, _C15, _C15), (24, _C15, _C15)]),
-    ('l', 'coco_25', [(2, _C31, _C31), (12, _C15, _C15)]),
-    ('s', 'coco', [(3, _C31, _C31)]),
+    ('b', 'coco', [(1, _C31, _C31, None), (4, _C30, _C30, None), (12, _C12, _C12, None), (15, _C41, _C41, _C8), (16, _C41, _C41, None), (20, _C15, _C15, None),
+                   (22, _C15, _C15, _C3), (32, _C20, _C20, None)]),
+    ('l', 'coco_25', [(2, _C31, _C31, None), (12, _C41, _C41, None), (16, _C15, _C15, None), (17, _C15, _C15, _C3), (24, _C20, _C20, None)]),
+    ('s', 'coco', [(3, _C31, _C31, None)]),
 ])
 def test_small_batch_tile_rule_is_bit_identical(variant, dataset, cases):
     """Round 5: below the 8-phase regime the residual GEMMs run on 32 x 64 / 64 x 64 tiles with TWO k-blocks per barrier (<= 256 tiles), on the 4-stage 64 x 64 ring
-    (<= 512 tiles) or on the 3-stage 128 x 64 tile (12-28 crops) -- vitpose_api.hip gemm().  Same k order: every crop must equal the max_batch = 8 path bit for bit
-    (whose own GEMMs are 128 x 128 / 4-stage 64 x 64 tiles), and the kernels must be the ones the rule names."""
+    (<= 512 tiles) or on the 3-stage 128 x 64 tile -- tile_rules.hip pick_gemm2_tile.  Round 6: 96 x 64 tiles between the two (<= 448 tiles), one round of 8-wave
+    192 x 128 tiles beyond 512 tiles of 128 x 64; mlp.fc1 on one round of 256 x 256 tiles (ragged last m-tile) / on the default tile where the 128 x 128 tiles would
+    overflow the resident slots.  Same k order: every crop must equal the max_batch = 8 path bit for bit (whose own GEMMs are 128 x 128 / 4-stage 64 x 64 tiles),
+    and the kernels must be the ones the rule names."""
     shp, sd, _ = weights(variant, dataset)
-    nmax = max(n for n, _, _ in cases)
+    nmax = max(c[0] for c in cases)
     crops = synthetic_crops(nmax, 91, 'blobs')
     crops[1::2] = synthetic_crops(len(crops[1::2]), 92, 'noise')
     small = VitPoseHip(shp, sd, dtype='fp16', max_batch=8)
     ref = small.infer(crops) if nmax > 8 else small.infer(np.concatenate([crops, synthetic_crops(8 - nmax, 93, 'noise')]))[:nmax]
     small.close()
-    for n, proj, fc2 in cases:
+    for n, proj, fc2, fc1 in cases:
         eng = VitPoseHip(shp, sd, dtype='fp16', max_batch=n)
         out = eng.infer(crops[:n])
         out2 = eng.infer(crops[:n])                      # second sighting of the chunk: the hipGraph replay (<= 16 crops)
-        kp, kf = eng.profile_kernel('gemm_proj'), eng.profile_kernel('gemm_fc2')
+        kp, kf, k1 = eng.profile_kernel('gemm_proj'), eng.profile_kernel('gemm_fc2'), eng.profile_kernel('gemm_fc1')
         eng.close()
-        assert proj in kp and fc2 in kf, (n, kp, kf)
+        assert proj in kp and fc2 in kf and (fc1 is None or fc1 in k1), (n, kp, kf, k1)
         assert np.array_equal(out, ref[:n]) and np.array_equal(out2, ref[:n]), f'{variant} batch {n} ({kp} / {kf}): {(out != ref[:n]).any(axis=(1, 2)).sum()} crops differ'
 
 

@@ -191,13 +191,15 @@ def test_gemm2_tile_selection_over_every_batch_size():
     """The rule that picks the 2-phase kernel's tile configuration (tile_rules.hip pick_gemm2_tile, through the host-only tap vp_dbg_gemm2_pick) walked over every
     batch size 1..400 of every model and every GEMM of the path.  Invariants: only configurations the PRODUCT library instantiates; the deep rings (4-stage 64 x 64,
     3-stage 128 x 64, the two-k-blocks-per-barrier configurations) only where ALL their tiles are resident at once (one round) -- except the round-2 long-K case --;
-    two k-blocks per barrier only for an even number of k-blocks; the default 192 x 128 tile from 384 tiles on; and the operating points measured in round 5
-    (profiles/small_batch_r5.txt) keep their kernels."""
+    two k-blocks per barrier only for an even number of k-blocks; the default 192 x 128 tile from 384 tiles on -- and below wherever the 128 x 128 tiles would
+    overflow the 512 resident slots --, except the one-round 256 x 256 tile for a wide GEMM with more than 512 such tiles; the 96 x 64 / 128 x 64 / one-round
+    192 x 128 ladder of the residual GEMMs beyond 512 tiles of 64 x 64 (round 6); and the operating points measured in rounds 5-6
+    (profiles/small_batch_r5.txt, profiles/small_batch_r6.txt) keep their kernels."""
     lib = capi.load_library()
     gm = C.c_int32()
     # Cfg id -> (BM, BN, resident workgroups on 256 CUs, two k-blocks per barrier)
     cfgs = {8: (192, 128, 512, False), 11: (192, 128, 512, False), 1: (128, 128, 512, False), 9: (64, 64, 1280, False), 12: (64, 64, 512, False),
-            15: (128, 64, 512, False), 30: (64, 64, 256, True), 31: (32, 64, 512, True), 20: (192, 128, 256, False)}
+            15: (128, 64, 512, False), 30: (64, 64, 256, True), 31: (32, 64, 512, True), 20: (192, 128, 256, False), 3: (256, 256, 256, False), 41: (96, 64, 512, False)}
 
     def pick(epi, M, N, K):
         v = lib.vp_dbg_gemm2_pick(epi, M, N, K, C.byref(gm))
@@ -214,12 +216,23 @@ def test_gemm2_tile_selection_over_every_batch_size():
                 bm, bn, slots, two = cfgs[v]
                 tiles = -(-m // bm) * -(-N // bn) * par
                 t192 = -(-m // 192) * -(-N // 128) * par
+                t128 = -(-m // 128) * -(-N // 128) * par
+                t64, t96x64, t128x64 = -(-m // 64) * -(-N // 64) * par, -(-m // 96) * -(-N // 64) * par, -(-m // 128) * -(-N // 64) * par
                 if t192 >= 384:
-                    assert v == (11 if epi == 6 else 8) and g == (8 if epi in (0, 1) else 0), (D, n, epi, v, g)
+                    # round 6: a wide GEMM with more than 512 tiles of 192 x 128 (a second, mostly empty round of 2 workgroups per CU) on ONE round of 256 x 256 tiles
+                    one_round_256 = epi in (0, 1) and t192 > 512 and K >= 768 and K % 128 == 0 and N % 256 == 0 and -(-m // 256) * (N // 256) <= 256
+                    assert v == (3 if one_round_256 else 11 if epi == 6 else 8) and g == (8 if epi in (0, 1) else 0), (D, n, epi, v, g)
                     continue
-                assert v not in (8, 11) and g == (8 if v == 20 else 0)
-                if v == 20:   # round 6: one round of 192 x 128 tiles where 128 x 128 tiles would need a second, mostly empty one
-                    assert epi in (0, 1) and K >= 1024 and tiles <= 256 and -(-m // 128) * -(-N // 128) > 256 and m % 192 == 0
+                if epi in (0, 1, 6) and t128 > 512:   # round 6: 128 x 128 tiles beyond the 512 resident slots -> the default tile (its tiles fit them)
+                    assert v == (11 if epi == 6 else 8) and tiles <= 512 and g == (8 if epi in (0, 1) else 0), (D, n, epi, v, g)
+                    continue
+                assert v not in (8, 11, 3) and g == (8 if v == 20 and epi in (0, 1) else 0), (D, n, epi, v, g)
+                if v == 20 and epi in (0, 1):   # round 6: one round of 192 x 128 tiles where 128 x 128 tiles would need a second, mostly empty one
+                    assert K >= 1024 and tiles <= 256 and t128 > 256 and m % 192 == 0
+                if epi == 6 and t64 > 512:   # round 6: the ladder of the residual GEMMs beyond the 512 resident 64 x 64 tiles
+                    assert v == (41 if t96x64 <= 448 else 15 if t128x64 <= 512 else 20 if t192 <= 256 else 1), (D, n, v)
+                else:
+                    assert v != 41 and (v != 20 or epi in (0, 1))
                 if v == 1:
                     assert tiles >= 256
                 if v in (15, 30, 31) or (v == 12 and K < 2048):
@@ -230,19 +243,23 @@ def test_gemm2_tile_selection_over_every_batch_size():
                     assert tiles <= 256
                 if two:
                     assert K % 128 == 0
-                if v == 15:
-                    assert epi == 6 and -(-m // 64) * -(-N // 64) > 512
+                if v in (15, 41):
+                    assert epi == 6 and t64 > 512 and tiles <= slots
                 if v == 9:
                     assert -(-m // 64) * -(-N // 64) * par > 512 and K < 2048
     # operating points of round 5 (in situ, profiles/small_batch_r5.txt): (qkv, fc1, proj, fc2)
     enc = lambda D, n: tuple(pick(e, 192 * n, N, K)[0] for e, N, K in ((0, 3 * D, D), (1, 4 * D, D), (6, D, D), (6, D, 4 * D)))
     assert enc(1024, 1) == (30, 30, 31, 31) and enc(1024, 2) == (12, 12, 31, 31) and enc(1024, 4) == (9, 9, 30, 30)      # ViTPose-L
     assert enc(1024, 8) == (20, 20, 12, 12) and enc(1024, 7)[:2] == (20, 20) and enc(1280, 8)[:2] == (20, 1) and enc(1024, 6)[:2] == (9, 20)   # round 6: one round of 192 x 128 tiles
-    assert enc(1024, 12) == (1, 8, 15, 15) and enc(1024, 16)[2:] == (15, 15) and enc(1024, 24)[2:] == (1, 1)
+    assert enc(1024, 12) == (1, 8, 41, 41) and enc(1024, 16)[2:] == (15, 15) and enc(1024, 24)[2:] == (20, 20)      # round 6 (calls 18-19): 96 x 64 at 11-14 crops, one round of 192 x 128 at 22-32
+    assert enc(1024, 11) == (1, 8, 41, 41) and enc(1024, 17)[1] == 3 and enc(1024, 21)[1:] == (3, 15, 15) and enc(1024, 22)[1] == 8 and enc(1024, 32)[2:] == (20, 20)
+    assert enc(1024, 40)[2:] == (1, 1) and enc(1024, 44)[2:] == (11, 11)
     assert enc(768, 1) == (31, 30, 31, 31) and enc(768, 4) == (12, 9, 30, 30) and enc(768, 8) == (9, 1, 12, 12)          # ViTPose-B
-    assert enc(768, 12)[2:] == (12, 12) and enc(768, 16)[2:] == (15, 15) and enc(768, 24)[2:] == (15, 15) and enc(768, 32)[2:] == (1, 1)
+    assert enc(768, 12)[2:] == (12, 12) and enc(768, 16)[2:] == (41, 41) and enc(768, 20)[2:] == (15, 15) and enc(768, 24)[2:] == (15, 15) and enc(768, 32)[2:] == (20, 20)
+    assert enc(768, 15) == (1, 8, 41, 41) and enc(768, 22)[1] == 3 and enc(768, 27)[1] == 3 and enc(768, 29)[1] == 8 and enc(768, 52)[2:] == (1, 1) and enc(768, 60)[2:] == (11, 11)
     assert enc(1280, 1) == (30, 30, 31, 31) and enc(1280, 4)[2:] == (30, 30) and enc(1280, 8)[2:] == (12, 12) and enc(1280, 12)[2:] == (15, 15)   # ViTPose-H
-    assert enc(384, 1) == (31, 31, 31, 31) and enc(384, 8) == (12, 9, 30, 30)                                            # ViTPose-S
+    assert enc(1280, 10)[1:] == (8, 41, 41) and enc(1280, 14)[1] == 3 and enc(1280, 20)[2:] == (20, 20) and enc(1280, 32)[2:] == (1, 1) and enc(1280, 36)[2:] == (11, 11)
+    assert enc(384, 1) == (31, 31, 31, 31) and enc(384, 8) == (12, 9, 30, 30) and enc(384, 32)[2:] == (41, 41) and enc(384, 40)[0] == 8   # ViTPose-S
     assert enc(768, 256) == (8, 8, 11, 11)                                                                                # BASELINE batch: the default tile (before the 8-phase kernel takes over)
 
 
