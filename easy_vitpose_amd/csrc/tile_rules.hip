@@ -75,12 +75,19 @@ Tile2Pick pick_gemm2_tile(int epi, int M, int N, int K) {
     const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128) * par_;
     const bool wide = epi == vp::EPI_BIAS || epi == vp::EPI_BIAS_GELU;
     if (t192 >= 384) {
-        // Round 6 (profiles/small_batch_r6.txt call 18): more than 512 tiles of 192 x 128 are a second, mostly empty round of the 2 workgroups per CU; while 256 x 256 tiles
-        // (ragged last m-tile) are still ONE round of 256, the 2-phase 256 x 256 tile runs the wide GEMM where the 8-phase kernel has no tile for the row count:
-        // ViTPose-L 17-21 crops mlp.fc1 48.5 -> 38.5 us (step -9 ... -10.7 %), -B 22-27 crops 40 -> 33-35 us (-5 ... -7 %); bit-identical (same k order).
-        if (wide && t192 > 512 && K >= 768 && K % 128 == 0 && N % 256 == 0 && (long)((M + 255) / 256) * (N / 256) <= 256) {
+        // Round 6 (profiles/small_batch_r6.txt calls 18-21): more than 512 tiles of 192 x 128 are a second, mostly empty round of the 2 workgroups per CU.  Where the 8-phase
+        // kernel has no tile for the row count (it takes the GEMM first, gemm()), every choice below keeps the k order (bit-identical):
+        //   * <= 256 tiles of 256 x 256 (ragged last m-tile): ONE round of the 2-phase 256 x 256 tile (Cfg3).  Wide GEMMs: ViTPose-L 17-21 crops mlp.fc1 48.5 -> 38.5 us (step
+        //     -9 ... -10.7 %), -B 22-27 crops -5 ... -7 %, -H 13-15 crops -5 ... -7.6 %, -S 43-55 crops -2 ... -3.6 %.  Residual GEMMs (57-85 crops of ViTPose-L, 86-113 of -B that are
+        //     no multiple of 4): mlp.fc2 140 -> 116-139 us, step -2.3 ... -6.2 %; with 272 such tiles it loses (+20 %): the rule asks for one round;
+        //   * else a wide GEMM whose 128 x 128 tiles still fit two rounds of the 512 slots (ViTPose-S attn.qkv at 57-75 crops: 25.0 -> 21-24 us, step -0.8 ... -3.1 %): 128 x 128.
+        const bool enc = wide || epi == vp::EPI_BIAS_RESID_LN;
+        if (enc && t192 > 512 && K >= 384 && K % 128 == 0 && N % 256 == 0 && (long)((M + 255) / 256) * (N / 256) <= 256) {
             tp.variant = 3;
-            tp.group_m = 8;
+            tp.group_m = wide ? 8 : 0;
+        } else if (wide && t192 > 512 && t128 <= 1024) {
+            tp.variant = 1;
+            tp.group_m = 0;
         }
         return tp;
     }

@@ -379,15 +379,15 @@ _C41, _C20, _C3, _C8 = '<96, 64, 64, 48, 32, 4, 0', '<192, 128, 64, 48, 64, 3, 1
 @pytest.mark.usefixtures('one_launch_family')
 @pytest.mark.parametrize('variant,dataset,cases', [
     ('b', 'coco', [(1, _C31, _C31, None), (4, _C30, _C30, None), (12, _C12, _C12, None), (15, _C41, _C41, _C8), (16, _C41, _C41, None), (20, _C15, _C15, None),
-                   (22, _C15, _C15, _C3), (32, _C20, _C20, None)]),
+                   (22, _C15, _C15, _C3), (32, _C20, _C20, None), (86, _C3, _C3, None)]),
     ('l', 'coco_25', [(2, _C31, _C31, None), (12, _C41, _C41, None), (16, _C15, _C15, None), (17, _C15, _C15, _C3), (24, _C20, _C20, None)]),
-    ('s', 'coco', [(3, _C31, _C31, None)]),
+    ('s', 'coco', [(3, _C31, _C31, None), (43, _C15, _C15, _C3)]),
 ])
 def test_small_batch_tile_rule_is_bit_identical(variant, dataset, cases):
     """Round 5: below the 8-phase regime the residual GEMMs run on 32 x 64 / 64 x 64 tiles with TWO k-blocks per barrier (<= 256 tiles), on the 4-stage 64 x 64 ring
     (<= 512 tiles) or on the 3-stage 128 x 64 tile -- tile_rules.hip pick_gemm2_tile.  Round 6: 96 x 64 tiles between the two (<= 448 tiles), one round of 8-wave
-    192 x 128 tiles beyond 512 tiles of 128 x 64; mlp.fc1 on one round of 256 x 256 tiles (ragged last m-tile) / on the default tile where the 128 x 128 tiles would
-    overflow the resident slots.  Same k order: every crop must equal the max_batch = 8 path bit for bit (whose own GEMMs are 128 x 128 / 4-stage 64 x 64 tiles),
+    192 x 128 tiles beyond 512 tiles of 128 x 64; mlp.fc1 -- and, at 86 crops of ViTPose-B, the residual GEMMs -- on one round of 256 x 256 tiles (ragged last m-tile) / on the
+    default tile where the 128 x 128 tiles would overflow the resident slots.  Same k order: every crop must equal the max_batch = 8 path bit for bit (whose own GEMMs are 128 x 128 / 4-stage 64 x 64 tiles),
     and the kernels must be the ones the rule names."""
     shp, sd, _ = weights(variant, dataset)
     nmax = max(c[0] for c in cases)

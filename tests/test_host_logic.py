@@ -219,9 +219,12 @@ def test_gemm2_tile_selection_over_every_batch_size():
                 t128 = -(-m // 128) * -(-N // 128) * par
                 t64, t96x64, t128x64 = -(-m // 64) * -(-N // 64) * par, -(-m // 96) * -(-N // 64) * par, -(-m // 128) * -(-N // 64) * par
                 if t192 >= 384:
-                    # round 6: a wide GEMM with more than 512 tiles of 192 x 128 (a second, mostly empty round of 2 workgroups per CU) on ONE round of 256 x 256 tiles
-                    one_round_256 = epi in (0, 1) and t192 > 512 and K >= 768 and K % 128 == 0 and N % 256 == 0 and -(-m // 256) * (N // 256) <= 256
-                    assert v == (3 if one_round_256 else 11 if epi == 6 else 8) and g == (8 if epi in (0, 1) else 0), (D, n, epi, v, g)
+                    # round 6: an encoder GEMM with more than 512 tiles of 192 x 128 (a second, mostly empty round of 2 workgroups per CU) on ONE round of 256 x 256 tiles
+                    # (ragged last m-tile); else a wide GEMM on 128 x 128 tiles while those fit two rounds of the 512 slots
+                    one_round_256 = epi in (0, 1, 6) and t192 > 512 and K >= 384 and K % 128 == 0 and N % 256 == 0 and -(-m // 256) * (N // 256) <= 256
+                    two_rounds_128 = not one_round_256 and epi in (0, 1) and t192 > 512 and t128 <= 1024
+                    assert v == (3 if one_round_256 else 1 if two_rounds_128 else 11 if epi == 6 else 8), (D, n, epi, v)
+                    assert g == (8 if epi in (0, 1) and v != 1 else 0), (D, n, epi, v, g)
                     continue
                 if epi in (0, 1, 6) and t128 > 512:   # round 6: 128 x 128 tiles beyond the 512 resident slots -> the default tile (its tiles fit them)
                     assert v == (11 if epi == 6 else 8) and tiles <= 512 and g == (8 if epi in (0, 1) else 0), (D, n, epi, v, g)
@@ -253,13 +256,15 @@ def test_gemm2_tile_selection_over_every_batch_size():
     assert enc(1024, 8) == (20, 20, 12, 12) and enc(1024, 7)[:2] == (20, 20) and enc(1280, 8)[:2] == (20, 1) and enc(1024, 6)[:2] == (9, 20)   # round 6: one round of 192 x 128 tiles
     assert enc(1024, 12) == (1, 8, 41, 41) and enc(1024, 16)[2:] == (15, 15) and enc(1024, 24)[2:] == (20, 20)      # round 6 (calls 18-19): 96 x 64 at 11-14 crops, one round of 192 x 128 at 22-32
     assert enc(1024, 11) == (1, 8, 41, 41) and enc(1024, 17)[1] == 3 and enc(1024, 21)[1:] == (3, 15, 15) and enc(1024, 22)[1] == 8 and enc(1024, 32)[2:] == (20, 20)
-    assert enc(1024, 40)[2:] == (1, 1) and enc(1024, 44)[2:] == (11, 11)
+    assert enc(1024, 40)[2:] == (1, 1) and enc(1024, 44)[2:] == (11, 11) and enc(1024, 65)[2:] == (3, 3) and enc(1024, 85)[2:] == (3, 3) and enc(1024, 86)[2:] == (11, 11)   # calls 20-21
     assert enc(768, 1) == (31, 30, 31, 31) and enc(768, 4) == (12, 9, 30, 30) and enc(768, 8) == (9, 1, 12, 12)          # ViTPose-B
     assert enc(768, 12)[2:] == (12, 12) and enc(768, 16)[2:] == (41, 41) and enc(768, 20)[2:] == (15, 15) and enc(768, 24)[2:] == (15, 15) and enc(768, 32)[2:] == (20, 20)
     assert enc(768, 15) == (1, 8, 41, 41) and enc(768, 22)[1] == 3 and enc(768, 27)[1] == 3 and enc(768, 29)[1] == 8 and enc(768, 52)[2:] == (1, 1) and enc(768, 60)[2:] == (11, 11)
     assert enc(1280, 1) == (30, 30, 31, 31) and enc(1280, 4)[2:] == (30, 30) and enc(1280, 8)[2:] == (12, 12) and enc(1280, 12)[2:] == (15, 15)   # ViTPose-H
     assert enc(1280, 10)[1:] == (8, 41, 41) and enc(1280, 14)[1] == 3 and enc(1280, 20)[2:] == (20, 20) and enc(1280, 32)[2:] == (1, 1) and enc(1280, 36)[2:] == (11, 11)
+    assert enc(768, 86)[2:] == (3, 3) and enc(768, 113)[2:] == (3, 3) and enc(768, 114)[2:] == (11, 11)
     assert enc(384, 1) == (31, 31, 31, 31) and enc(384, 8) == (12, 9, 30, 30) and enc(384, 32)[2:] == (41, 41) and enc(384, 40)[0] == 8   # ViTPose-S
+    assert enc(384, 43)[1] == 3 and enc(384, 55)[1] == 3 and enc(384, 57)[0] == 1 and enc(384, 75)[0] == 1 and enc(384, 76)[0] == 8
     assert enc(768, 256) == (8, 8, 11, 11)                                                                                # BASELINE batch: the default tile (before the 8-phase kernel takes over)
 
 
