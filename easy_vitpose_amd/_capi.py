@@ -27,7 +27,7 @@ SYMBOLS = ['vp_abi_version', 'vp_create', 'vp_load_weights', 'vp_infer', 'vp_inf
            'vp_infer_tokens', 'vp_decode_only', 'vp_stream', 'vp_synchronize', 'vp_set_profiling',
            'vp_reset_profile', 'vp_get_profile', 'vp_profile_kernel', 'vp_group_peer_access_missing', 'vp_destroy', 'vp_last_error',
            'vp_dbg_gemm', 'vp_dbg_attention', 'vp_dbg_layernorm', 'vp_dbg_deconv', 'vp_dbg_gemm_case', 'vp_dbg_crop_prep',
-           'vp_dbg_group_plan', 'vp_dbg_group_trace', 'vp_dbg_gemm8_pick', 'vp_dbg_gemm2_pick', 'vp_dbg_splitk_pick', 'vp_dbg_fp8_gemm', 'vp_dbg_mx_gemm', 'vp_dbg_host_e4m3', 'vp_dbg_gemm_fp8_case', 'vp_dbg_qkvattn']
+           'vp_dbg_group_plan', 'vp_dbg_group_trace', 'vp_dbg_gemm8_pick', 'vp_dbg_gemm2_pick', 'vp_dbg_splitk_pick', 'vp_dbg_run_batch', 'vp_dbg_fp8_gemm', 'vp_dbg_mx_gemm', 'vp_dbg_host_e4m3', 'vp_dbg_gemm_fp8_case', 'vp_dbg_qkvattn']
 
 
 class HipExtensionMissing(RuntimeError):
@@ -133,6 +133,7 @@ def load_library():
     lib.vp_dbg_gemm8_pick.argtypes = [C.c_int32] * 4 + [C.c_void_p]
     lib.vp_dbg_gemm2_pick.argtypes = [C.c_int32] * 4 + [C.c_void_p]
     lib.vp_dbg_splitk_pick.argtypes = [C.c_int32] * 3 + [C.c_void_p]
+    lib.vp_dbg_run_batch.argtypes = [C.c_int32] * 3
     lib.vp_dbg_group_trace.argtypes = [C.c_int32] * 3 + [C.c_void_p, C.c_int32]
     lib.vp_dbg_fp8_gemm.argtypes = [C.c_int32] * 4 + [C.c_void_p] * 7
     lib.vp_dbg_mx_gemm.argtypes = [C.c_int32] * 4 + [C.c_void_p] * 7

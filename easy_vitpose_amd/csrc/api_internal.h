@@ -72,6 +72,7 @@ struct vp_ctx {
     bool fuse_ln = true;              // LayerNorm folded into the GEMMs on both sides of it (VP_FUSE_LN=0: standalone passes)
     bool fuse_qkv_attn = true;        // head dim 64, even batches of >= 128 (pair, head) tiles: attn.qkv + attention core in one kernel (VP_FUSE_QKV_ATTN=0: two launches)
     int g8_bm192 = 3;                 // the 8-phase kernel's 192 x 256 tile is a candidate for: 1 = the residual GEMMs, 2 = the wide GEMMs
+    bool pad_batch = true;            // the encoder runs the next multiple of 4 crops where that buys an 8-phase tile (tile_rules.hip pick_run_batch; VP_PAD_BATCH=0: never)
     bool g8_cost_model = true;        // tile selection with the round-4 extensions (VP_G8_COST=0: the round-3 thresholds + the 192-row fallback)
     bool deconv_parity_fast = true;   // head: the four output parities of a deconv tile run side by side on one XCD (VP_DECONV_PARITY_FAST=0: parity-major launch order)
     float *ln_part = nullptr, *rowstat = nullptr;   // partial row statistics [M][D/64][2], (mean, rstd) [M][2]
@@ -224,6 +225,7 @@ Tile2Pick pick_gemm2_tile(int epi, int M, int N, int K);
 // split-K of a residual GEMM (attn.proj, mlp.fc2) at small batches: S k ranges on tile configuration `variant` (S = 1: no split)
 struct SplitKPick { int S, variant; };
 SplitKPick pick_splitk(int M, int N, int K);
+int pick_run_batch(int n, int D, int limit, int bm192_mask, bool extended, int gemm8_mask);   // the batch the encoder runs for a chunk of n crops (>= n, a multiple of 4 when padded)
 constexpr int SPLITK_MAX_S = 8, SPLITK_MAX_CROPS = 32;
 
 // ---- vitpose_api.hip: one GEMM of the path through the tile rules (also what the vp_dbg_gemm* taps launch)

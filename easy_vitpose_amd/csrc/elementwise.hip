@@ -16,11 +16,12 @@ namespace vp {
 // thread-per-output-chunk version fetched 2.1x the algorithmic bytes: 64-byte pieces of 128-byte lines).
 // FLIP: the crop is mirrored left-right on the fly (flip-test, topdown_heatmap_simple_head.py:195-218).
 template <class Ty, int FMT, bool FLIP>
-__global__ __launch_bounds__(256) void im2col_kernel(const void* __restrict__ in, uint16_t* __restrict__ out, int B) {
+__global__ __launch_bounds__(256) void im2col_kernel(const void* __restrict__ in, uint16_t* __restrict__ out, int B, int n_src) {
     constexpr int XS = 208;                                  // LDS row: x = -2 .. 205 (index x + 2)
     __shared__ __attribute__((aligned(16))) uint16_t tile[3 * 16 * XS];
     const int tid = threadIdx.x;
-    const int b = blockIdx.x >> 4, py = blockIdx.x & 15;
+    const int bo = blockIdx.x >> 4, py = blockIdx.x & 15;    // output crop bo reads source crop min(bo, n_src - 1): the rows of a padded encoder batch (vitpose_api.hip forward_chunk) repeat the last crop
+    const int b = min(bo, n_src - 1);
     const int ytop = 16 * py - 2;
     if (FMT == VP_INPUT_F32_NCHW) {
         // 3 channels x 16 rows x 48 float4
@@ -63,7 +64,7 @@ __global__ __launch_bounds__(256) void im2col_kernel(const void* __restrict__ in
         tile[(tid >> 1) * XS + (tid & 1)] = 0;
     }
     __syncthreads();
-    uint16_t* orow = out + ((size_t)b * 192 + py * 12) * 768;
+    uint16_t* orow = out + ((size_t)bo * 192 + py * 12) * 768;
     for (int id = tid; id < 12 * 96; id += 256) {
         const int px = id / 96, kc = id - px * 96;
         const int c = kc >> 5, ky = (kc & 31) >> 1, kx0 = (kc & 1) * 8;
@@ -71,13 +72,14 @@ __global__ __launch_bounds__(256) void im2col_kernel(const void* __restrict__ in
     }
 }
 
-hipError_t im2col_launch(int dtype, const void* crops, int fmt, uint16_t* out, int B, hipStream_t s, bool flip) {
+hipError_t im2col_launch(int dtype, const void* crops, int fmt, uint16_t* out, int B, hipStream_t s, bool flip, int n_src) {
     if (B <= 0) return hipSuccess;
+    if (n_src <= 0 || n_src > B) n_src = B;   // B output crops from n_src source crops (the last one repeated)
     const int grid = B * 16;   // one block per patch row
 #define VP_I2C(TY, F)                                                                                              \
     do {                                                                                                           \
-        if (flip) hipLaunchKernelGGL((im2col_kernel<TY, F, true>), dim3(grid), dim3(256), 0, s, crops, out, B);    \
-        else hipLaunchKernelGGL((im2col_kernel<TY, F, false>), dim3(grid), dim3(256), 0, s, crops, out, B);        \
+        if (flip) hipLaunchKernelGGL((im2col_kernel<TY, F, true>), dim3(grid), dim3(256), 0, s, crops, out, B, n_src);    \
+        else hipLaunchKernelGGL((im2col_kernel<TY, F, false>), dim3(grid), dim3(256), 0, s, crops, out, B, n_src);        \
     } while (0)
     if (fmt == VP_INPUT_F32_NCHW) {
         if (dtype == DT_F16) VP_I2C(F16, VP_INPUT_F32_NCHW); else VP_I2C(BF16, VP_INPUT_F32_NCHW);

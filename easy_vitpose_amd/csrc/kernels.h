@@ -183,7 +183,7 @@ hipError_t qkv_head_major80_launch(const uint16_t* w, const float* b, const floa
 hipError_t layernorm_launch(int dtype, const float* x, const float* gamma, const float* beta,
                             uint16_t* out16, float* out32, int M, int D, hipStream_t s, size_t plane = 0);
 // crops -> im2col patch matrix [B*192, 768] 16-bit (k = c*256 + ky*16 + kx, zero border of 2 px)
-hipError_t im2col_launch(int dtype, const void* crops, int input_format, uint16_t* out, int B, hipStream_t s, bool flip = false);
+hipError_t im2col_launch(int dtype, const void* crops, int input_format, uint16_t* out, int B, hipStream_t s, bool flip = false, int n_src = 0);   // n_src < B: output crops n_src .. B - 1 repeat source crop n_src - 1
 // flip-test: hm = 0.5 (hm + flip_back(hm_flipped)); partner[k] = mirror joint of k (k itself if unpaired)
 hipError_t flip_merge_launch(float* hm, const float* hm_flipped, const int32_t* partner, int N, int K, int shift, hipStream_t s);
 

@@ -144,9 +144,64 @@ SplitKPick pick_splitk(int M, int N, int K) {
     return {1, 0};
 }
 
+// (BM, BN, workgroups resident on 256 CUs) of a 2-phase tile configuration the rule above can return
+static bool tile2_dims(int variant, int& bm, int& bn, int& slots) {
+    switch (variant) {
+        case 8: case 11: bm = 192; bn = 128; slots = 512; return true;
+        case 1: bm = 128; bn = 128; slots = 512; return true;
+        case 3: bm = 256; bn = 256; slots = 256; return true;
+        case 9: bm = 64; bn = 64; slots = 1280; return true;
+        case 12: bm = 64; bn = 64; slots = 512; return true;
+        case 15: bm = 128; bn = 64; slots = 512; return true;
+        case 20: bm = 192; bn = 128; slots = 256; return true;
+        case 30: bm = 64; bn = 64; slots = 256; return true;
+        case 31: bm = 32; bn = 64; slots = 512; return true;
+        case 41: bm = 96; bn = 64; slots = 512; return true;
+    }
+    return false;
+}
+
+// Rounds x tile area x K of one MLP GEMM at M rows under the rules above: the persistent 8-phase kernel runs ceil(tiles / 256) full rounds (its 192-row tile priced x 1.08 as in
+// pick_gemm8_tile); a 2-phase launch ceil(tiles / resident slots) rounds, priced x 1.15 (measured: the 2-phase 256 x 256 tile 33 us against 30 for the same one-round launch on
+// the 8-phase kernel, the default tile 110 against 80-90).
+static double mlp_gemm_cost(int epi, int M, int N, int K, bool wide, int bm192_mask, bool extended, bool gemm8) {
+    if (gemm8) {
+        const G8Pick pk = pick_gemm8_tile(M, N, wide, bm192_mask, 448, extended);
+        if (pk.variant) return (double)((pk.tiles + 255) / 256) * pk.bm * pk.bn * (pk.bm == 192 ? 1.08 : 1.0) * K;
+    }
+    int bm = 192, bn = 128, slots = 512;
+    if (!tile2_dims(pick_gemm2_tile(epi, M, N, K).variant, bm, bn, slots)) return 0.0;
+    const long t = (long)((M + bm - 1) / bm) * ((N + bn - 1) / bn);
+    return (double)((t + slots - 1) / slots) * bm * bn * (slots / 256) * 1.15 * K;
+}
+
+// The batch the ENCODER runs for a chunk of n crops (round 6, profiles/small_batch_r6.txt calls 20 + 22): the 8-phase kernel's 256-row tiles need a row count that is a multiple
+// of 256 = a multiple of 4 crops, so a batch of 65 crops of ViTPose-L ran mlp.fc2 in 137 us on 516 2-phase tiles where 68 crops take 99 us -- the whole step 9.93 against 9.02 ms.
+// From 33 crops on the encoder therefore runs the next multiple of 4 crops (the padding rows repeat the last crop: im2col_launch n_src; every kernel of the path works row by row
+// or crop by crop, so the real crops' results are bit for bit those of the unpadded run: test_padded_encoder_batch_is_bit_identical) whenever the cost above of mlp.fc1 + mlp.fc2
+// drops by more than 5 % -- checked against the measured step times of every batch size in calls 17-20: 108 of the 112 padded sizes gain (2-9 %), 4 lose 1.0-4.2 %.  The head
+// and the decode run the real crops only.  A pure function of (n, D): tests/test_host_logic.py walks it through vp_dbg_run_batch.
+int pick_run_batch(int n, int D, int limit, int bm192_mask, bool extended, int gemm8_mask) {
+    const int n4 = (n + 3) / 4 * 4;
+    if (n < 33 || n4 == n || n4 > limit) return n;
+    auto cost = [&](int m) {
+        return mlp_gemm_cost(vp::EPI_BIAS_GELU, 192 * m, 4 * D, D, true, bm192_mask, extended, (gemm8_mask & 2) != 0) +
+               mlp_gemm_cost(vp::EPI_BIAS_RESID_LN, 192 * m, D, 4 * D, false, bm192_mask, extended, (gemm8_mask & 1) != 0);
+    };
+    const double c0 = cost(n), c1 = cost(n4);
+    return (c0 > 0.0 && c1 > 0.0 && c1 < 0.95 * c0) ? n4 : n;
+}
+
 }  // namespace vpi
 
 extern "C" {
+
+// HOST ONLY: the batch the encoder runs for a chunk of n crops of a model of embed dim D (pick_run_batch with the default switches; limit = the handle's padded workspace batch)
+VP_API int vp_dbg_run_batch(int32_t n, int32_t D, int32_t limit) {
+    if (n <= 0 || D <= 0) return VP_ERR_INVALID;
+    return pick_run_batch(n, D, limit, 3, true, 0x7);
+}
+
 
 // HOST ONLY: the 8-phase tile the selection rule of gemm() picks for an [M, N] output (wide: qkv / fc1; else the residual GEMMs); returns the
 // variant (0 = none: 2-phase kernels, 16 = 256 x 256, 17 = 256 x 192, 18 = 192 x 256) and its tile count

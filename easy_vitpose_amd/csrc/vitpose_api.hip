@@ -210,10 +210,14 @@ int gemm_fp8(vp_ctx* c, int fam, int epi, const uint8_t* A8, const uint8_t* a_sc
 namespace {
 
 // forward of one chunk (n <= max_batch) with device-resident crops; heatmaps land in c->hm
-int forward_chunk(vp_ctx* c, const void* d_crops, int fmt, int n, bool want_tokens, bool flip = false) {
-    const int D = c->D, M = n * 192;
-    const double in_b = (fmt == VP_INPUT_F32_NCHW ? 4.0 : 1.0) * n * 3.0 * 256 * 192;
-    LAUNCH(c, VP_PROF_IM2COL, 0.0, in_b + 2.0 * M * 768, vp::im2col_launch(c->dtype, d_crops, fmt, c->hid, n, c->stream, flip));
+int forward_chunk(vp_ctx* c, const void* d_crops, int fmt, int n_in, bool want_tokens, bool flip = false) {
+    const int D = c->D;
+    // the ENCODER's batch: n_in crops, or the next multiple of 4 where that buys the MLP GEMMs an 8-phase tile (tile_rules.hip pick_run_batch; rows n_in .. n - 1 repeat the
+    // last crop and are never read by the head); the fp8 mode pads its rows itself
+    const int n = (c->pad_batch && c->fuse_ln && !c->fp8) ? pick_run_batch(n_in, D, (c->maxb + 3) / 4 * 4, c->g8_bm192, c->g8_cost_model, c->gemm8_mask) : n_in;
+    const int M = n * 192;
+    const double in_b = (fmt == VP_INPUT_F32_NCHW ? 4.0 : 1.0) * n_in * 3.0 * 256 * 192;
+    LAUNCH(c, VP_PROF_IM2COL, 0.0, in_b + 2.0 * M * 768, vp::im2col_launch(c->dtype, d_crops, fmt, c->hid, n, c->stream, flip, n_in));
     int rc;
     size_t plane = 0;   // != 0: the residual stream c->x is held as two 16-bit planes (fused-LayerNorm path)
     const bool qkv_blocked = c->blocked_qkv && D / c->heads == 64;
@@ -347,16 +351,18 @@ int forward_chunk(vp_ctx* c, const void* d_crops, int fmt, int n, bool want_toke
         if ((rc = gemm(c, VP_PROF_GEMM_FC2, vp::EPI_BIAS_RESID, c->hid, b.w_fc2, b.b_fc2, c->x, c->x, M, D, 4 * D, D))) return rc;
     }
     }
-    LAUNCH(c, VP_PROF_LAYERNORM, 0.0, 6.0 * M * D,
-           vp::layernorm_launch(c->dtype, c->x, c->lnf_g, c->lnf_b, c->y, want_tokens ? c->tok : nullptr, M, D, c->stream, plane));
+    // last_norm, head and decode: the caller's n_in crops (the planes are laid out for the encoder's row count)
+    const int nh = n_in, Mh = nh * 192;
+    LAUNCH(c, VP_PROF_LAYERNORM, 0.0, 6.0 * Mh * D,
+           vp::layernorm_launch(c->dtype, c->x, c->lnf_g, c->lnf_b, c->y, want_tokens ? c->tok : nullptr, Mh, D, c->stream, plane));
     // head: tokens [n,16,12,D] (NHWC view of [n*192, D]) -> [n,32,24,256] -> [n,64,48,256] -> heatmaps [n,Kp,64,48]
-    if ((rc = gemm(c, VP_PROF_GEMM_DECONV, vp::EPI_DECONV, c->y, c->w_d1, c->b_d1, c->d1, nullptr, n * 192, 256, 4 * D, 256, 16, 12, D))) return rc;
+    if ((rc = gemm(c, VP_PROF_GEMM_DECONV, vp::EPI_DECONV, c->y, c->w_d1, c->b_d1, c->d1, nullptr, nh * 192, 256, 4 * D, 256, 16, 12, D))) return rc;
     // large batches: the final 1x1 conv rides in deconv2's epilogue (gemm.hip EPI_DECONV_FINAL, bit-identical heatmaps) and the
     // [n,64,48,256] tensor is never written; small batches keep the two launches on tiles that still fill 256 CUs
-    if (c->fuse_head && c->gemm_variant[VP_PROF_GEMM_DECONV] < 0 && (long)n * 12 >= 512)
-        return gemm(c, VP_PROF_GEMM_DECONV, vp::EPI_DECONV_FINAL, c->d1, c->w_d2, c->b_d2, nullptr, nullptr, n * 768, 256, 1024, 256, 32, 24, 256);
-    if ((rc = gemm(c, VP_PROF_GEMM_DECONV, vp::EPI_DECONV, c->d1, c->w_d2, c->b_d2, c->d2, nullptr, n * 768, 256, 1024, 256, 32, 24, 256))) return rc;
-    if ((rc = gemm(c, VP_PROF_GEMM_FINAL, vp::EPI_HEATMAP, c->d2, c->w_fin, c->b_fin, c->hm, nullptr, n * 3072, (int)c->fin_rows, 256, 0))) return rc;
+    if (c->fuse_head && c->gemm_variant[VP_PROF_GEMM_DECONV] < 0 && (long)nh * 12 >= 512)
+        return gemm(c, VP_PROF_GEMM_DECONV, vp::EPI_DECONV_FINAL, c->d1, c->w_d2, c->b_d2, nullptr, nullptr, nh * 768, 256, 1024, 256, 32, 24, 256);
+    if ((rc = gemm(c, VP_PROF_GEMM_DECONV, vp::EPI_DECONV, c->d1, c->w_d2, c->b_d2, c->d2, nullptr, nh * 768, 256, 1024, 256, 32, 24, 256))) return rc;
+    if ((rc = gemm(c, VP_PROF_GEMM_FINAL, vp::EPI_HEATMAP, c->d2, c->w_fin, c->b_fin, c->hm, nullptr, nh * 3072, (int)c->fin_rows, 256, 0))) return rc;
     return VP_OK;
 }
 
@@ -503,7 +509,7 @@ int vp_create(vp_handle* out, const vp_config* cfg) {
     if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) { c->err = hipGetErrorString(e); return bail(VP_ERR_HIP); }
     c->own_stream = c->stream;
     if (const char* f = getenv("VP_CALLER_STREAM")) c->caller_stream_max_n = atoi(f) == 1 ? 16 : atoi(f);   // 0 = always fence against the caller's stream with events
-    const size_t B = (size_t)c->maxb;
+    const size_t B = (size_t)((c->maxb + 3) / 4 * 4);   // workspaces: the encoder may run the next multiple of 4 crops (forward_chunk)
     // fp8 mode: workspaces indexed by token row are sized for the padded row count the MXFP8 GEMM tiles need
     c->Mp = std::max<size_t>((B * 192 + 255) / 256 * 256, 512);
     const size_t M = c->fp8 ? c->Mp : B * 192;
@@ -525,6 +531,7 @@ int vp_create(vp_handle* out, const vp_config* cfg) {
     if (const char* f = getenv("VP_FUSE_QKV_ATTN")) c->fuse_qkv_attn = atoi(f) != 0;
     if (const char* f = getenv("VP_DECONV_PARITY_FAST")) c->deconv_parity_fast = atoi(f) != 0;
     if (const char* f = getenv("VP_G8_COST")) c->g8_cost_model = atoi(f) != 0;
+    if (const char* f = getenv("VP_PAD_BATCH")) c->pad_batch = atoi(f) != 0;
     if (const char* f = getenv("VP_G8_BM192")) c->g8_bm192 = atoi(f);   // mask: 1 = residual GEMMs, 2 = wide GEMMs may take the 192 x 256 tile of the 8-phase kernel (0: never)
     if (const char* f = getenv("VP_SPLITK")) {   // 0 = off; "fc2:S:variant,proj:S:variant" = override the rule (measurement sweeps)
         if (!strchr(f, ':')) c->splitk_on = atoi(f) != 0;

@@ -287,6 +287,11 @@ VP_API int vp_dbg_gemm2_pick(int32_t epi, int32_t M, int32_t N, int32_t K, int32
 /* HOST ONLY: the split-K rule of the residual GEMMs at small batches (attn.proj / mlp.fc2 of [M, N] x K): returns the number of k ranges S (1 = the one-launch
  * residual epilogue; S > 1 = S partial products + the fixed-order reduction kernel), *variant (may be NULL) = the gemm.hip Cfg id of the partial products */
 VP_API int vp_dbg_splitk_pick(int32_t M, int32_t N, int32_t K, int32_t* variant);
+/* HOST ONLY: the batch the ENCODER runs for a chunk of n crops of a model of embed dim D (>= n; limit = the largest batch the workspaces hold).  From 33 crops on a chunk
+ * that is no multiple of 4 crops runs the next multiple of 4 where that moves mlp.fc1 / mlp.fc2 onto the 8-phase kernel's 256-row tiles (or saves a round of them): the padding
+ * rows repeat the last crop, every kernel works row by row or crop by crop, so the real crops' keypoints are bit for bit those of the unpadded run; the head and the decode run
+ * the real crops only.  VP_PAD_BATCH=0 switches the padding off. */
+VP_API int vp_dbg_run_batch(int32_t n, int32_t D, int32_t limit);
 /* The two-phase schedule of a group call -- HOST ONLY, stub members: the order in which group_run would submit to (+ (member + 1)) and
  * wait for (- (member + 1)) its members for n crops on w devices of max_batch maxb.  Within every round all submissions precede the
  * first wait: no member's enqueue waits for another member's compute.  Returns the trace length (also beyond `cap`); < 0 on bad arguments. */

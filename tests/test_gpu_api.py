@@ -363,8 +363,9 @@ def test_every_tile_choice_of_the_selection_rule_is_bit_identical():
         out = eng.infer(crops[:n])
         k1, k2 = eng.profile_kernel('gemm_fc1'), eng.profile_kernel('gemm_fc2')
         eng.close()
-        v1 = lib.vp_dbg_gemm8_pick(192 * n, 4 * shp.embed_dim, 1, 3, C.byref(t))
-        v2 = lib.vp_dbg_gemm8_pick(192 * n, shp.embed_dim, 0, 3, C.byref(t))
+        nr = lib.vp_dbg_run_batch(n, shp.embed_dim, (n + 3) // 4 * 4)   # round 6: the encoder may run the next multiple of 4 crops (tile_rules.hip pick_run_batch)
+        v1 = lib.vp_dbg_gemm8_pick(192 * nr, 4 * shp.embed_dim, 1, 3, C.byref(t))
+        v2 = lib.vp_dbg_gemm8_pick(192 * nr, shp.embed_dim, 0, 3, C.byref(t))
         assert names[v1] in k1 and names[v2] in k2, (n, v1, k1, v2, k2)
         seen.add((v1, v2))
         assert np.array_equal(out, ref[:n]), f'batch {n} ({k1} / {k2}): {(out != ref[:n]).any(axis=(1, 2)).sum()} crops differ from the max_batch = 8 path'
@@ -379,14 +380,14 @@ _C41, _C20, _C3, _C8 = '<96, 64, 64, 48, 32, 4, 0', '<192, 128, 64, 48, 64, 3, 1
 @pytest.mark.usefixtures('one_launch_family')
 @pytest.mark.parametrize('variant,dataset,cases', [
     ('b', 'coco', [(1, _C31, _C31, None), (4, _C30, _C30, None), (12, _C12, _C12, None), (15, _C41, _C41, _C8), (16, _C41, _C41, None), (20, _C15, _C15, None),
-                   (22, _C15, _C15, _C3), (32, _C20, _C20, None), (86, _C3, _C3, None)]),
+                   (22, _C15, _C15, _C3), (32, _C20, _C20, None), (113, _C3, _C3, None)]),   # 113: no multiple of 4 the padding rule (pick_run_batch) rounds up
     ('l', 'coco_25', [(2, _C31, _C31, None), (12, _C41, _C41, None), (16, _C15, _C15, None), (17, _C15, _C15, _C3), (24, _C20, _C20, None)]),
-    ('s', 'coco', [(3, _C31, _C31, None), (43, _C15, _C15, _C3)]),
+    ('s', 'coco', [(3, _C31, _C31, None)]),
 ])
 def test_small_batch_tile_rule_is_bit_identical(variant, dataset, cases):
     """Round 5: below the 8-phase regime the residual GEMMs run on 32 x 64 / 64 x 64 tiles with TWO k-blocks per barrier (<= 256 tiles), on the 4-stage 64 x 64 ring
     (<= 512 tiles) or on the 3-stage 128 x 64 tile -- tile_rules.hip pick_gemm2_tile.  Round 6: 96 x 64 tiles between the two (<= 448 tiles), one round of 8-wave
-    192 x 128 tiles beyond 512 tiles of 128 x 64; mlp.fc1 -- and, at 86 crops of ViTPose-B, the residual GEMMs -- on one round of 256 x 256 tiles (ragged last m-tile) / on the
+    192 x 128 tiles beyond 512 tiles of 128 x 64; mlp.fc1 -- and, at 113 crops of ViTPose-B, the residual GEMMs -- on one round of 256 x 256 tiles (ragged last m-tile) / on the
     default tile where the 128 x 128 tiles would overflow the resident slots.  Same k order: every crop must equal the max_batch = 8 path bit for bit (whose own GEMMs are 128 x 128 / 4-stage 64 x 64 tiles),
     and the kernels must be the ones the rule names."""
     shp, sd, _ = weights(variant, dataset)
@@ -404,6 +405,37 @@ def test_small_batch_tile_rule_is_bit_identical(variant, dataset, cases):
         eng.close()
         assert proj in kp and fc2 in kf and (fc1 is None or fc1 in k1), (n, kp, kf, k1)
         assert np.array_equal(out, ref[:n]) and np.array_equal(out2, ref[:n]), f'{variant} batch {n} ({kp} / {kf}): {(out != ref[:n]).any(axis=(1, 2)).sum()} crops differ'
+
+
+@pytest.mark.parametrize('variant,dataset,n,max_batch', [('b', 'coco', 43, 43), ('b', 'coco', 86, 86), ('l', 'coco_25', 65, 65), ('s', 'coco', 45, 48), ('b', 'coco', 90, 43)])
+def test_padded_encoder_batch_is_bit_identical(variant, dataset, n, max_batch, monkeypatch):
+    """Round 6: from 33 crops on the encoder runs the next multiple of 4 crops where that buys mlp.fc1 / mlp.fc2 an 8-phase tile (tile_rules.hip pick_run_batch; the padding
+    rows repeat the last crop, the head and the decode run the real crops).  Keypoints AND heatmaps of the real crops must equal the unpadded run (VP_PAD_BATCH=0) bit for bit --
+    also when the handle's max_batch is the odd size itself (workspaces rounded up in vp_create) and when a call is split into chunks (90 crops on max_batch 43: 43 + 43 + 4);
+    and the padded run must really have taken the 8-phase kernel."""
+    shp, sd, _ = weights(variant, dataset)
+    crops = synthetic_crops(n, 83, 'blobs')
+    crops[1::2] = synthetic_crops(len(crops[1::2]), 84, 'noise')
+    monkeypatch.setenv('VP_PAD_BATCH', '0')
+    eng = VitPoseHip(shp, sd, dtype='fp16', max_batch=max_batch)
+    ref_kp = eng.infer(crops)
+    ref_hm = eng.heatmaps(crops[:min(n, max_batch)])
+    k_ref = eng.profile_kernel('gemm_fc1') + ' | ' + eng.profile_kernel('gemm_fc2')
+    eng.close()
+    monkeypatch.delenv('VP_PAD_BATCH')
+    eng = VitPoseHip(shp, sd, dtype='fp16', max_batch=max_batch)
+    kp = eng.infer(crops)
+    kp2 = eng.infer(crops)                     # again: warm workspaces
+    hm = eng.heatmaps(crops[:min(n, max_batch)])   # last forward = one full chunk: its kernels are the ones profile_kernel names
+    k_pad = eng.profile_kernel('gemm_fc1') + ' | ' + eng.profile_kernel('gemm_fc2')
+    eng.close()
+    import ctypes as C
+    run = capi.load_library().vp_dbg_run_batch(min(n, max_batch), shp.embed_dim, (max_batch + 3) // 4 * 4)
+    print(f'[padded encoder batch] {variant} x {n} (max_batch {max_batch}): encoder runs {run} crops per full chunk; unpadded {k_ref}; padded {k_pad}')
+    assert run > min(n, max_batch) and run % 4 == 0
+    assert 'gemm8_kernel' in k_pad
+    assert np.array_equal(kp, ref_kp) and np.array_equal(kp2, ref_kp), f'{(kp != ref_kp).any(axis=(1, 2)).sum()} crops differ'
+    assert np.array_equal(hm, ref_hm)
 
 
 def test_deconv_parity_order_is_bit_identical(monkeypatch):

@@ -41,6 +41,7 @@ CASES = [
     ('l', 'coco_25', 64, 2, {'gemm_qkv': 'qkvattn_kernel<F16>', 'gemm_fc1': 'gemm8_kernel<F16, 1, G8<256, 256>>',   # qkv + attention fused: 32 pairs x 16 heads = 512 tiles, K = 1024
                               'gemm_fc2': 'gemm8_kernel<F16, 6, G8<256, 192>>'}),                                # fc2: 192 tiles of 256 x 256 would fill 75 % -> 256 tiles of 192 x 256
     ('h', 'wholebody', 127, 2, {'gemm_qkv': 'gemm8_kernel<F16, 9, G8<256, 192>>', 'gemm_fc1': 'gemm8_kernel<F16, 1, G8<256, 192>>', 'gemm_fc2': 'gemm8_kernel<F16, 6, G8<256, 192>>'}),   # 24 384 rows: only the 192-row tile divides them
+    ('l', 'coco_25', 65, 2, {'gemm_qkv': 'qkvattn_kernel<F16>', 'gemm_fc1': 'gemm8_kernel<F16, 1, G8<256, 256>>', 'gemm_fc2': 'gemm8_kernel<F16, 6, G8<256, 256>>'}),   # round 6: the encoder runs 68 crops (pick_run_batch): 256-row tiles for a batch that is no multiple of 4
     ('b', 'coco', 85, 2, {'gemm_fc1': 'gemm8_kernel<F16, 1, G8<256, 192>>', 'gemm_fc2': 'gemm8_kernel<F16, 6, G8<256, 192>>'}),   # fc2: 255 tiles = 255 workgroups, one round (a grid that is no multiple of 8)
     ('s', 'coco', 256, 4, {'gemm_fc1': 'gemm8_kernel<F16, 1, G8<256, 192>>'}),   # 1536 tiles of 192 x 256 = 6 rounds against 4.5 -> 5 rounds of 256 x 256
     ('b', 'coco', 88, 2, {'gemm_fc2': 'gemm8_kernel<F16, 6, G8<256, 256>>'}),   # 198 tiles = one round of 198 workgroups
@@ -50,7 +51,9 @@ CASES = [
 
 @pytest.mark.usefixtures('one_launch_family')
 @pytest.mark.parametrize('variant,dataset,B,n_oracle,expect', CASES, ids=[f'{c[0]}-{c[1]}-{c[2]}' for c in CASES])
-def test_production_batch_under_assertion(golden_dir, variant, dataset, B, n_oracle, expect):
+def test_production_batch_under_assertion(golden_dir, variant, dataset, B, n_oracle, expect, monkeypatch):
+    if (variant, B) == ('h', 127):   # this case is here for the 192-row tiles of a row count no 256-row tile divides: keep the encoder on 127 crops (round 6 would run 128)
+        monkeypatch.setenv('VP_PAD_BATCH', '0')
     z = np.load(os.path.join(golden_dir, f'peaked_{variant}_{dataset}.npz'))
     ng = int(z['n'])
     shp = model_shape(variant, dataset)

@@ -268,6 +268,29 @@ def test_gemm2_tile_selection_over_every_batch_size():
     assert enc(768, 256) == (8, 8, 11, 11)                                                                                # BASELINE batch: the default tile (before the 8-phase kernel takes over)
 
 
+def test_padded_encoder_batch_rule_over_every_batch_size():
+    """Round 6: the batch the encoder runs for a chunk of n crops (tile_rules.hip pick_run_batch through the host-only tap vp_dbg_run_batch) walked over every batch size of
+    every model.  Invariants: never fewer crops than asked, at most 3 more, a multiple of 4 whenever it differs, never below 33 crops, never beyond the workspace limit,
+    multiples of 4 untouched; a padded batch always has an 8-phase tile for mlp.fc1 or mlp.fc2 (that is what the padding buys).  And the sizes measured in
+    profiles/small_batch_r6.txt (calls 20, 22) keep their choices."""
+    lib = capi.load_library()
+    tiles = C.c_int32()
+    for D in (384, 768, 1024, 1280):
+        for n in range(1, 641):
+            r = lib.vp_dbg_run_batch(n, D, 1024)
+            assert n <= r <= n + 3, (D, n, r)
+            if r != n:
+                assert n >= 33 and r % 4 == 0 and n % 4 != 0, (D, n, r)
+                assert lib.vp_dbg_gemm8_pick(192 * r, 4 * D, 1, 3, C.byref(tiles)) or lib.vp_dbg_gemm8_pick(192 * r, D, 0, 3, C.byref(tiles)), (D, n, r)
+            assert lib.vp_dbg_run_batch(n, D, n) == n                        # a handle of max_batch n that is a multiple of 4 has no room to pad
+            assert lib.vp_dbg_run_batch(n, D, (n + 3) // 4 * 4) == r         # ... and one whose workspaces are rounded up (vp_create) does
+    run = lambda D, n: lib.vp_dbg_run_batch(n, D, 1024)
+    assert [run(768, n) for n in (8, 32, 43, 44, 45, 47, 85, 86, 87, 113, 117)] == [8, 32, 44, 44, 48, 48, 85, 88, 88, 113, 117]     # ViTPose-B
+    assert [run(1024, n) for n in (21, 33, 35, 41, 65, 67, 69, 83)] == [21, 36, 36, 41, 68, 68, 72, 84]                              # ViTPose-L
+    assert [run(1280, n) for n in (31, 53, 66)] == [31, 56, 68] and [run(384, n) for n in (43, 55, 60)] == [44, 56, 60]              # ViTPose-H, -S
+    assert run(768, 256) == 256 and run(1280, 128) == 128 and run(1024, 64) == 64                                                     # the BASELINE batches are multiples of 4
+
+
 def test_gemm8_tile_selection_over_every_batch_size():
     """The rule that picks the 8-phase kernel's tile (tile_rules.hip pick_gemm8_tile, through the host-only tap vp_dbg_gemm8_pick) walked over every
     batch size 1..640 of every model.  Invariants: a picked tile divides the matrix and the tap reports its tile count; the wide GEMMs never get the
