@@ -105,11 +105,14 @@ struct vp_ctx {
     int graph_victim = 0;
     bool fuse_head = true;            // VP_FUSE_HEAD=0: deconv2 and the final 1x1 conv as two launches at every batch size
     int graph_max_n = 16;
+    bool fold_rule = true;            // beyond graph_max_n_stats crops: fold per consumer where its tile keeps its occupancy with the statistics area (forward_chunk; off when VP_FOLD_STATS is set)
     int graph_max_n_stats = 8;        // batches of <= this many crops: the consumer GEMMs (qkv, fc1) merge the LayerNorm partial statistics of their tile rows
                                       // themselves (once per row and tile, in the prologue: gemm.hip) and the 2 x depth ln_finalize launches disappear -- same
                                       // ln_merge, bit-identical.  Measured (profiles/fold_stats_r3.txt): -7...-12 % per step at 1-8 crops, +0...+20 % at
                                       // 16-48 (every column tile merges its rows again): threshold 8.  VP_FOLD_STATS=n moves it (0 = always ln_finalize).
                                       // Round 6 (merge on a register copy, profiles/small_batch_r6.txt call 11): -2.6 ... -6.5 % against ln_finalize at 1-8 crops.
+                                      // Round 6, call 25: the '+0 ... +20 %' beyond 8 crops was the statistics area behind the default tile's 80 KiB ring (one workgroup per CU
+                                      // instead of two), not the merge: beyond this threshold each consumer folds on its own where its tile keeps its occupancy (fold_rule).
                                       // Round 2 merged per LANE in the epilogue (16 x redundant): slower than ln_finalize even at 8 crops (3.89 vs 2.97 ms).
     // split-K for the residual GEMMs of small batches (round 6; tile_rules.hip pick_splitk, gemm.hip EPI_PARTIAL, elementwise.hip splitk_reduce_kernel): fp32 partial
     // products [S][M][D] of up to splitk_rows token rows.  VP_SPLITK=0 switches it off (the parity test flips it); VP_SPLITK="fc2:S:variant,proj:S:variant" overrides the rule.

@@ -272,29 +272,44 @@ int forward_chunk(vp_ctx* c, const void* d_crops, int fmt, int n_in, bool want_t
         // 1.800, 1 crop 1.172 -> 1.111; beyond 8 crops it still loses (every column tile merges its rows again; ViTPose-H's fused qkv + attention tile needs rowstat):
         // profiles/small_batch_r6.txt call 11)
         const bool fold_stats = n <= c->graph_max_n_stats;
-        auto finalize = [&]() -> int {
-            if (fold_stats) return VP_OK;
+        // Round 6 (profiles/small_batch_r6.txt call 25): beyond 8 crops the fold did not lose because of the merge but because the (mean, rstd) area behind the ring pushes the
+        // 80 KiB ring of the default 192 x 128 tile over half the CU's LDS -- ONE workgroup per CU instead of two (+9 ... +12 % per step).  Per consumer (attn.qkv reads LayerNorm-1,
+        // mlp.fc1 LayerNorm-2): fold where its GEMM runs on a 2-phase tile that keeps its occupancy with the area (every configuration but the 80 KiB-ring ones), i.e. not on the
+        // 8-phase kernel, not in a fused qkv + attention kernel (they read rowstat): ViTPose-S 9-28 crops -6.5 ... -8 %, -B 9-14 -2 ... -6 %, -L 9-10 -2.3 %; same code, same bits.
+        auto folds = [&](int fam, int epi, int N, int g8bit) {
+            if (fold_stats) return true;
+            if (!c->fold_rule || n > 64 || c->gemm_variant[fam] >= 0) return false;
+            if ((c->gemm8_mask & g8bit) && pick_gemm8_tile(M, N, true, c->g8_bm192, 448, c->g8_cost_model).variant) return false;
+            const int v = pick_gemm2_tile(epi, M, N, D).variant;
+            return v != 8 && v != 11;
+        };
+        // attn.qkv + attention core as ONE kernel per (pair of crops, head) from 108 tiles on (qkvattn.hip; bit-identical y; an odd batch's last crop fills both halves of its pair)
+        // 128 - 1536 tiles: profiles/qkvattn_r4.txt.  Below (round 6, profiles/small_batch_r6.txt call 16): 108-120 tiles win or tie (ViTPose-B 17-20 crops -0.6 ... -6.5 %: at 19-20
+        // crops the unfused qkv is 540 tiles of 128 x 128 on 512 slots; ViTPose-L 13-14 crops equal); 96 tiles and fewer lose (-B 16 crops +-0, 12 crops +3 %, -L 9-12 crops +2 ... +7 %)
+        static const long qa_min_tiles = [] { const char* e = getenv("VP_QA_MIN_TILES"); return e ? atol(e) : 108L; }();
+        // head dim 80: one crop x one head per 192 x 256 tile of the 8-phase kernel (gemm8.hip EPI_QKV_ATTN; bit-identical y), from 192 tiles on
+        static const long qa80_min_tiles = [] { const char* e = getenv("VP_QA80_MIN_TILES"); return e ? atol(e) : 192L; }();   // wins from 12 crops x 16 heads on (profiles/qkvattn80_r5.txt)
+        const bool has_qkvh = c->L > 0 && c->blocks[0].w_qkvh != nullptr;
+        const bool want80 = has_qkvh && c->heads * 80 == D && (long)n * c->heads >= qa80_min_tiles, want64 = has_qkvh && c->heads * 64 == D && (long)((n + 1) / 2) * c->heads >= qa_min_tiles;
+        const bool fold1 = fold_stats || (!want80 && !want64 && folds(VP_PROF_GEMM_QKV, vp::EPI_BIAS, 3 * D, 4));   // LayerNorm-1 -> attn.qkv
+        const bool fold2 = folds(VP_PROF_GEMM_FC1, vp::EPI_BIAS_GELU, 4 * D, 2);                                       // LayerNorm-2 -> mlp.fc1
+        auto finalize = [&](bool folded) -> int {
+            if (folded) return VP_OK;
             LAUNCH(c, VP_PROF_LAYERNORM, 0.0, 8.0 * M * tiles + 8.0 * M, vp::ln_finalize_launch(c->ln_part, c->rowstat, M, tiles, D, c->stream));
             return VP_OK;
         };
         if ((rc = gemm(c, VP_PROF_GEMM_PATCH, vp::EPI_POS_LN, c->hid, c->w_patch, c->b_zero, c->x, c->pos, M, D, 768, D, 0, 0, 0, &prod))) return rc;
-        if ((rc = finalize())) return rc;
+        if ((rc = finalize(fold1))) return rc;
         for (int l = 0; l < c->L; ++l) {
             const Block& b = c->blocks[l];
             LnFuse cq; cq.rowstat = c->rowstat; cq.ln_s = b.s_qkv; cq.reverse = (c->order_mask & 1) != 0; cq.out_blocked = qkv_blocked;
-            if (fold_stats) { cq.rowstat = nullptr; cq.ln_part = c->ln_part; cq.ln_tiles = D / 64; }
-            // attn.qkv + attention core as ONE kernel per (pair of crops, head) from 108 tiles on (qkvattn.hip; bit-identical y; an odd batch's last crop fills both halves of its pair)
-            // 128 - 1536 tiles: profiles/qkvattn_r4.txt.  Below (round 6, profiles/small_batch_r6.txt call 16): 108-120 tiles win or tie (ViTPose-B 17-20 crops -0.6 ... -6.5 %: at 19-20
-            // crops the unfused qkv is 540 tiles of 128 x 128 on 512 slots; ViTPose-L 13-14 crops equal); 96 tiles and fewer lose (-B 16 crops +-0, 12 crops +3 %, -L 9-12 crops +2 ... +7 %)
-            static const long qa_min_tiles = [] { const char* e = getenv("VP_QA_MIN_TILES"); return e ? atol(e) : 108L; }();
+            if (fold1) { cq.rowstat = nullptr; cq.ln_part = c->ln_part; cq.ln_tiles = D / 64; }
             vp::QkvAttnArgs qa{};
             qa.x_hi = xh; qa.wh = b.w_qkvh; qa.bh = b.b_qkvh; qa.sh = b.s_qkvh; qa.rowstat = c->rowstat; qa.y = c->y;
             qa.npairs = (n + 1) / 2; qa.ncrops = n; qa.heads = c->heads; qa.D = D;   // odd n: the last crop fills both halves of its pair
             qa.scale_log2e = (1.0f / sqrtf(64.0f)) * 1.4426950408889634f;
             // (a shape the fused kernel rejects -- a chunk beyond its 32-bit row offsets, fewer than 8 tiles under a lowered VP_QA_MIN_TILES -- falls through
             // to the gemm + attention pair below, the way gemm() falls back when gemm8_supported says no: ADVICE r4)
-            // head dim 80: one crop x one head per 192 x 256 tile of the 8-phase kernel (gemm8.hip EPI_QKV_ATTN; bit-identical y), from 192 tiles on
-            static const long qa80_min_tiles = [] { const char* e = getenv("VP_QA80_MIN_TILES"); return e ? atol(e) : 192L; }();   // wins from 12 crops x 16 heads on (profiles/qkvattn80_r5.txt)
             vp::GemmArgs g80{};
             if (b.w_qkvh && c->heads * 80 == D) {
                 g80.A = xh; g80.W = b.w_qkvh; g80.bias = b.b_qkvh; g80.ln_s = b.s_qkvh; g80.rowstat = c->rowstat; g80.out = c->y;
@@ -306,14 +321,14 @@ int forward_chunk(vp_ctx* c, const void* d_crops, int fmt, int n_in, bool want_t
                 g80.attn_scale_log2e = (1.0f / sqrtf(80.0f)) * 1.4426950408889634f;
                 g80.ablate = c->gemm_ablate | c->fam_ablate[VP_PROF_GEMM_QKV];
             }
-            if (g80.A && !fold_stats && (long)n * c->heads >= qa80_min_tiles && c->gemm_variant[VP_PROF_GEMM_QKV] < 0 && vp::gemm8_supported(vp::EPI_QKV_ATTN, g80, 256, 192)) {
+            if (g80.A && !fold1 && (long)n * c->heads >= qa80_min_tiles && c->gemm_variant[VP_PROF_GEMM_QKV] < 0 && vp::gemm8_supported(vp::EPI_QKV_ATTN, g80, 256, 192)) {
                 char desc[192];
                 desc[0] = 0;
                 g80.desc = desc; g80.desc_cap = (int)sizeof(desc);
                 LAUNCH(c, VP_PROF_GEMM_QKV, 2.0 * M * 3.0 * D * D + 4.0 * 192 * 192 * (double)D * n, 2.0 * M * D + 2.0 * 3 * D * (double)D + 2.0 * M * D,
                        vp::gemm_launch(c->dtype, vp::EPI_QKV_ATTN, g80, c->stream));
                 if (desc[0] && c->kernel_desc[VP_PROF_GEMM_QKV] != desc) c->kernel_desc[VP_PROF_GEMM_QKV] = desc;
-            } else if (b.w_qkvh && c->heads * 64 == D && !fold_stats && (long)((n + 1) / 2) * c->heads >= qa_min_tiles && c->gemm_variant[VP_PROF_GEMM_QKV] < 0 && vp::qkvattn_supported(qa)) {
+            } else if (b.w_qkvh && c->heads * 64 == D && !fold1 && (long)((n + 1) / 2) * c->heads >= qa_min_tiles && c->gemm_variant[VP_PROF_GEMM_QKV] < 0 && vp::qkvattn_supported(qa)) {
                 char desc[96];
                 desc[0] = 0;
                 LAUNCH(c, VP_PROF_GEMM_QKV, 2.0 * M * 3.0 * D * D + 4.0 * 192 * 192 * (double)D * n, 2.0 * M * D + 2.0 * 3 * D * (double)D + 2.0 * M * D,
@@ -326,13 +341,13 @@ int forward_chunk(vp_ctx* c, const void* d_crops, int fmt, int n_in, bool want_t
             }
             LnFuse pp = prod; pp.reverse = (c->order_mask & 2) != 0;
             if ((rc = gemm(c, VP_PROF_GEMM_PROJ, vp::EPI_BIAS_RESID_LN, c->y, b.w_proj, b.b_proj, c->x, c->x, M, D, D, D, 0, 0, 0, &pp))) return rc;
-            if ((rc = finalize())) return rc;
+            if ((rc = finalize(fold2))) return rc;
             LnFuse c1; c1.rowstat = c->rowstat; c1.ln_s = b.s_fc1; c1.out_blocked = c->blocked_hid; c1.reverse = (c->order_mask & 4) != 0;
-            if (fold_stats) { c1.rowstat = nullptr; c1.ln_part = c->ln_part; c1.ln_tiles = D / 64; }
+            if (fold2) { c1.rowstat = nullptr; c1.ln_part = c->ln_part; c1.ln_tiles = D / 64; }
             if ((rc = gemm(c, VP_PROF_GEMM_FC1, vp::EPI_BIAS_GELU, xh, b.w_fc1, b.b_fc1, c->hid, nullptr, M, 4 * D, D, 4 * D, 0, 0, 0, &c1))) return rc;
             LnFuse p2 = prod; p2.a_blocked = c->blocked_hid; p2.reverse = (c->order_mask & 8) != 0;
             if ((rc = gemm(c, VP_PROF_GEMM_FC2, vp::EPI_BIAS_RESID_LN, c->hid, b.w_fc2, b.b_fc2, c->x, c->x, M, D, 4 * D, D, 0, 0, 0, &p2))) return rc;
-            if (l + 1 < c->L && (rc = finalize())) return rc;   // last block: last_norm below is a standalone pass
+            if (l + 1 < c->L && (rc = finalize(fold1))) return rc;   // last block: last_norm below is a standalone pass
         }
     } else {
     if ((rc = gemm(c, VP_PROF_GEMM_PATCH, vp::EPI_POS, c->hid, c->w_patch, c->b_zero, c->x, c->pos, M, D, 768, D))) return rc;
@@ -526,7 +541,7 @@ int vp_create(vp_handle* out, const vp_config* cfg) {
     if (const char* f = getenv("VP_PERSIST")) c->persist_gemm = atoi(f) != 0;
     if (const char* f = getenv("VP_GRAPH")) c->graph_max_n = atoi(f) == 1 ? 16 : atoi(f);   // 0 = off, 1 = default, n > 1: capture chunks of up to n crops
     if (const char* f = getenv("VP_FUSE_HEAD")) c->fuse_head = atoi(f) != 0;
-    if (const char* f = getenv("VP_FOLD_STATS")) c->graph_max_n_stats = atoi(f);
+    if (const char* f = getenv("VP_FOLD_STATS")) { c->graph_max_n_stats = atoi(f); c->fold_rule = false; }   // an explicit threshold: fold up to that many crops, nowhere else
     if (const char* f = getenv("VP_BLOCKED_QKV")) c->blocked_qkv = atoi(f) != 0;
     if (const char* f = getenv("VP_FUSE_QKV_ATTN")) c->fuse_qkv_attn = atoi(f) != 0;
     if (const char* f = getenv("VP_DECONV_PARITY_FAST")) c->deconv_parity_fast = atoi(f) != 0;

@@ -183,6 +183,37 @@ def test_small_batch_statistics_fold_is_bit_identical(monkeypatch, variant, data
     assert ref_launches == 2 * (2 * shp.depth + 1) and launches == 2, (ref_launches, launches)   # only last_norm is left (two forward passes)
 
 
+@pytest.mark.parametrize('variant,dataset,n,folded', [('s', 'coco', 12, 'both'), ('s', 'coco', 28, 'both'), ('b', 'coco', 12, 'both'), ('b', 'coco', 16, 'ln1'), ('l', 'coco_25', 12, 'ln1'),
+                                                       ('h', 'wholebody', 10, 'ln1'), ('b', 'coco', 20, 'none')])
+def test_statistics_fold_rule_beyond_8_crops(monkeypatch, variant, dataset, n, folded):
+    """Round 6: beyond 8 crops the consumers' statistics merge is chosen PER CONSUMER (vitpose_api.hip forward_chunk): attn.qkv (LayerNorm-1) / mlp.fc1 (LayerNorm-2) fold where
+    their GEMM runs on a 2-phase tile that keeps its occupancy with the (mean, rstd) area behind its ring -- not the 80 KiB ring of the default 192 x 128 tile (one workgroup
+    per CU instead of two), not the 8-phase kernel, not a fused qkv + attention kernel.  Same ln_merge: heatmaps and keypoints equal the ln_finalize path (VP_FOLD_STATS=0)
+    bit for bit, and exactly the expected ln_finalize launches disappear."""
+    shp, sd, _ = weights(variant, dataset)
+    crops = synthetic_crops(n, 35, 'blobs')
+    crops[1::2] = synthetic_crops(len(crops[1::2]), 36, 'noise')
+    monkeypatch.setenv('VP_GRAPH', '0')
+    monkeypatch.setenv('VP_FOLD_STATS', '0')
+    eng = VitPoseHip(shp, sd, dtype='fp16', max_batch=n)
+    eng.set_profiling(True)
+    ref_kp, ref_hm = eng.infer(crops), eng.heatmaps(crops)
+    ref_launches = eng.profile()['layernorm']['launches']
+    eng.close()
+    monkeypatch.delenv('VP_FOLD_STATS')
+    eng = VitPoseHip(shp, sd, dtype='fp16', max_batch=n)
+    eng.set_profiling(True)
+    kp, hm = eng.infer(crops), eng.heatmaps(crops)
+    launches = eng.profile()['layernorm']['launches']
+    kernels = {f: eng.profile_kernel(f) for f in ('gemm_qkv', 'gemm_fc1')}
+    eng.close()
+    L = shp.depth
+    expect = {'both': 2, 'ln1': 2 * (L + 1), 'none': 2 * (2 * L + 1)}[folded]   # two forward passes; last_norm always launches
+    print(f'[fold rule] {variant} x {n}: layernorm-family launches {ref_launches} -> {launches} ({folded}); {kernels}')
+    assert ref_launches == 2 * (2 * L + 1) and launches == expect, (ref_launches, launches, kernels)
+    assert np.array_equal(hm, ref_hm) and np.array_equal(kp, ref_kp)
+
+
 @pytest.mark.parametrize('variant,dataset,dtype,n', [('s', 'coco', 'fp16', 64), ('s', 'wholebody', 'fp16', 48), ('b', 'coco_25', 'bf16', 44)])
 def test_fused_head_is_bit_identical(monkeypatch, variant, dataset, dtype, n):
     """Batches of >= 43 crops run deconv2 + final 1x1 conv as ONE kernel (gemm.hip EPI_DECONV_FINAL: the 256-channel activations
