@@ -286,12 +286,18 @@ int forward_chunk(vp_ctx* c, const void* d_crops, int fmt, int n_in, bool want_t
         // attn.qkv + attention core as ONE kernel per (pair of crops, head) from 108 tiles on (qkvattn.hip; bit-identical y; an odd batch's last crop fills both halves of its pair)
         // 128 - 1536 tiles: profiles/qkvattn_r4.txt.  Below (round 6, profiles/small_batch_r6.txt call 16): 108-120 tiles win or tie (ViTPose-B 17-20 crops -0.6 ... -6.5 %: at 19-20
         // crops the unfused qkv is 540 tiles of 128 x 128 on 512 slots; ViTPose-L 13-14 crops equal); 96 tiles and fewer lose (-B 16 crops +-0, 12 crops +3 %, -L 9-12 crops +2 ... +7 %)
+        //   Call 26: with the per-consumer statistics fold (below) the two-launch path saves its LayerNorm-1 ln_finalize launches wherever the qkv GEMM's tile folds, and wins back
+        //   108-127 tiles there (ViTPose-B 17-18 crops -1.8 / -2.2 %, -L 13-14 crops -2.9 / -3.4 %); where that GEMM would run on the default tile (-B 19-20) the fused kernel keeps them.
+        static const bool qa_min_set = getenv("VP_QA_MIN_TILES") != nullptr;
         static const long qa_min_tiles = [] { const char* e = getenv("VP_QA_MIN_TILES"); return e ? atol(e) : 108L; }();
         // head dim 80: one crop x one head per 192 x 256 tile of the 8-phase kernel (gemm8.hip EPI_QKV_ATTN; bit-identical y), from 192 tiles on
         static const long qa80_min_tiles = [] { const char* e = getenv("VP_QA80_MIN_TILES"); return e ? atol(e) : 192L; }();   // wins from 12 crops x 16 heads on (profiles/qkvattn80_r5.txt)
         const bool has_qkvh = c->L > 0 && c->blocks[0].w_qkvh != nullptr;
-        const bool want80 = has_qkvh && c->heads * 80 == D && (long)n * c->heads >= qa80_min_tiles, want64 = has_qkvh && c->heads * 64 == D && (long)((n + 1) / 2) * c->heads >= qa_min_tiles;
-        const bool fold1 = fold_stats || (!want80 && !want64 && folds(VP_PROF_GEMM_QKV, vp::EPI_BIAS, 3 * D, 4));   // LayerNorm-1 -> attn.qkv
+        const bool qkv_can_fold = folds(VP_PROF_GEMM_QKV, vp::EPI_BIAS, 3 * D, 4);
+        const long pair_tiles = (long)((n + 1) / 2) * c->heads;
+        const bool want80 = has_qkvh && c->heads * 80 == D && (long)n * c->heads >= qa80_min_tiles;
+        const bool want64 = has_qkvh && c->heads * 64 == D && pair_tiles >= qa_min_tiles && (qa_min_set || pair_tiles >= 128 || !qkv_can_fold);
+        const bool fold1 = fold_stats || (!want80 && !want64 && qkv_can_fold);   // LayerNorm-1 -> attn.qkv
         const bool fold2 = folds(VP_PROF_GEMM_FC1, vp::EPI_BIAS_GELU, 4 * D, 2);                                       // LayerNorm-2 -> mlp.fc1
         auto finalize = [&](bool folded) -> int {
             if (folded) return VP_OK;
@@ -328,7 +334,7 @@ int forward_chunk(vp_ctx* c, const void* d_crops, int fmt, int n_in, bool want_t
                 LAUNCH(c, VP_PROF_GEMM_QKV, 2.0 * M * 3.0 * D * D + 4.0 * 192 * 192 * (double)D * n, 2.0 * M * D + 2.0 * 3 * D * (double)D + 2.0 * M * D,
                        vp::gemm_launch(c->dtype, vp::EPI_QKV_ATTN, g80, c->stream));
                 if (desc[0] && c->kernel_desc[VP_PROF_GEMM_QKV] != desc) c->kernel_desc[VP_PROF_GEMM_QKV] = desc;
-            } else if (b.w_qkvh && c->heads * 64 == D && !fold1 && (long)((n + 1) / 2) * c->heads >= qa_min_tiles && c->gemm_variant[VP_PROF_GEMM_QKV] < 0 && vp::qkvattn_supported(qa)) {
+            } else if (want64 && b.w_qkvh && !fold1 && c->gemm_variant[VP_PROF_GEMM_QKV] < 0 && vp::qkvattn_supported(qa)) {
                 char desc[96];
                 desc[0] = 0;
                 LAUNCH(c, VP_PROF_GEMM_QKV, 2.0 * M * 3.0 * D * D + 4.0 * 192 * 192 * (double)D * n, 2.0 * M * D + 2.0 * 3 * D * (double)D + 2.0 * M * D,

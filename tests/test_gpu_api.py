@@ -184,12 +184,13 @@ def test_small_batch_statistics_fold_is_bit_identical(monkeypatch, variant, data
 
 
 @pytest.mark.parametrize('variant,dataset,n,folded', [('s', 'coco', 12, 'both'), ('s', 'coco', 28, 'both'), ('b', 'coco', 12, 'both'), ('b', 'coco', 16, 'ln1'), ('l', 'coco_25', 12, 'ln1'),
-                                                       ('h', 'wholebody', 10, 'ln1'), ('b', 'coco', 20, 'none')])
+                                                       ('h', 'wholebody', 10, 'ln1'), ('b', 'coco', 18, 'ln1'), ('l', 'coco_25', 14, 'ln1'), ('b', 'coco', 20, 'none')])
 def test_statistics_fold_rule_beyond_8_crops(monkeypatch, variant, dataset, n, folded):
     """Round 6: beyond 8 crops the consumers' statistics merge is chosen PER CONSUMER (vitpose_api.hip forward_chunk): attn.qkv (LayerNorm-1) / mlp.fc1 (LayerNorm-2) fold where
     their GEMM runs on a 2-phase tile that keeps its occupancy with the (mean, rstd) area behind its ring -- not the 80 KiB ring of the default 192 x 128 tile (one workgroup
     per CU instead of two), not the 8-phase kernel, not a fused qkv + attention kernel.  Same ln_merge: heatmaps and keypoints equal the ln_finalize path (VP_FOLD_STATS=0)
-    bit for bit, and exactly the expected ln_finalize launches disappear."""
+    bit for bit, and exactly the expected ln_finalize launches disappear.  At 108-127 (pair, head) tiles (ViTPose-B 17-18 crops, -L 13-14) the two-launch qkv + attention path
+    keeps attn.qkv because its tile folds; at 19-20 crops of ViTPose-B (default tile: no fold) the fused kernel takes it."""
     shp, sd, _ = weights(variant, dataset)
     crops = synthetic_crops(n, 35, 'blobs')
     crops[1::2] = synthetic_crops(len(crops[1::2]), 36, 'noise')
@@ -211,6 +212,7 @@ def test_statistics_fold_rule_beyond_8_crops(monkeypatch, variant, dataset, n, f
     expect = {'both': 2, 'ln1': 2 * (L + 1), 'none': 2 * (2 * L + 1)}[folded]   # two forward passes; last_norm always launches
     print(f'[fold rule] {variant} x {n}: layernorm-family launches {ref_launches} -> {launches} ({folded}); {kernels}')
     assert ref_launches == 2 * (2 * L + 1) and launches == expect, (ref_launches, launches, kernels)
+    assert ('qkvattn' in kernels['gemm_qkv']) == (folded == 'none'), kernels
     assert np.array_equal(hm, ref_hm) and np.array_equal(kp, ref_kp)
 
 
