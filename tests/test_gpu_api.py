@@ -134,6 +134,24 @@ def test_small_batch_graph_replay_is_bit_identical(monkeypatch):
     assert not np.array_equal(o2, ref)
 
 
+@pytest.mark.parametrize('variant,dataset,dtype,n', [('b', 'coco', 'bf16', 9), ('s', 'coco', 'bf16', 9), ('b', 'coco', 'fp16', 9), ('l', 'coco_25', 'fp16', 12), ('s', 'coco', 'bf16', 30), ('h', 'wholebody', 'fp16', 10)])
+def test_small_batches_are_run_to_run_identical(variant, dataset, dtype, n):
+    """A fresh handle, four forwards of the same crops: heatmaps bit for bit.  Round 6 (profiles/small_batch_r6.txt call 28): a gemm.hip whose epilogue had one more wave-uniform
+    branch + barrier in front of the LDS staging lost this on the BF16 64 x 64 2-stage qkv kernel (ViTPose-B / -S at 9 crops) -- on the plain path, with several workgroups per
+    CU -- while every fp16 build stayed stable; the layout test caught it by accident, this one is there on purpose (eager launches and hipGraph replay, both dtypes, the tile
+    families of 9-30 crops)."""
+    shp, sd, _ = weights(variant, dataset)
+    crops = synthetic_crops(n, 19, 'blobs')
+    crops[1::2] = synthetic_crops(len(crops[1::2]), 20, 'noise')
+    eng = VitPoseHip(shp, sd, dtype=dtype, max_batch=n)
+    hms = [eng.heatmaps(crops) for _ in range(4)]
+    kps = [eng.infer(crops) for _ in range(4)]          # <= 16 crops: eager, capture, replay, replay
+    eng.close()
+    assert all(np.array_equal(hms[0], h) for h in hms[1:]), [int((hms[0] != h).sum()) for h in hms[1:]]
+    assert all(np.array_equal(kps[0], k) for k in kps[1:])
+    assert np.isfinite(hms[0]).all()
+
+
 @pytest.mark.parametrize('variant,dataset,dtype,n', [('b', 'coco', 'fp16', 44), ('l', 'coco_25', 'fp16', 5), ('b', 'coco', 'bf16', 9)])
 def test_blocked_qkv_layout_is_bit_identical(monkeypatch, variant, dataset, dtype, n):
     """Head dim 64: the qkv GEMM writes its output in the 64 x 64-blocked layout and the attention kernel reads a (crop, head)'s q / k / v as three
